@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: decoded Mbit/s on batched 768-bit DAB FIC frames.
+
+One "step" = one pass of the hot path (K=7 r=1/4 Viterbi: ACS + traceback) over one
+batch of 65536 FIC frames (BASELINE.json configs[1]) that is already resident in HBM
+in the device format (1 byte per soft symbol).  N>1 = one process per GPU, every rank
+decodes its own 65536-frame shard (independent frames, no data-path collective: weak
+scaling); value = all ranks' decoded bits / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the decode kernel against the HBM
+peak with the ALGORITHMIC bytes (3192 B per FIC frame: 3096 symbol bytes in + 96 out);
+`cpu_baseline` is this repo's own AVX2 port of the same integer specification
+(oracle/vit_avx2.c, "port") timed on the host cores of the same box, on the same frames.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import _vitpkg  # noqa: E402
+
+FRAMEBITS = 768
+TAIL = 6
+POLYS = (109, 79, 83, 109)  # viterbi-benchmark.cpp:64
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_frames(nframes, framebits, seed, device):
+    """Reference-style synthetic input (viterbi-benchmark.cpp:293-311): random bits ->
+    DAB mother code -> AWGN at Eb/N0 = 3 dB, sample = 127.5 + 32*N(+-gain,1), clip 0..255.
+    Built on the GPU with a seeded torch generator; returns uint8 [nframes, 4*(framebits+6)]."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    T = framebits + TAIL
+    bits = torch.randint(0, 2, (nframes, framebits), generator=g, device=device, dtype=torch.int32)
+    bits = torch.cat([bits, torch.zeros((nframes, TAIL), dtype=torch.int32, device=device)], dim=1)
+    # sr(t) = last 7 input bits, newest in bit 0
+    padded = torch.cat([torch.zeros((nframes, 6), dtype=torch.int32, device=device), bits], dim=1)
+    sr = torch.zeros((nframes, T), dtype=torch.int32, device=device)
+    for k in range(7):
+        sr |= padded[:, 6 - k:6 - k + T] << k
+    hard = torch.empty((nframes, T, 4), dtype=torch.float32, device=device)
+    for j, poly in enumerate(POLYS):
+        x = sr & poly
+        x = x ^ (x >> 4)
+        x = x ^ (x >> 2)
+        x = x ^ (x >> 1)
+        hard[:, :, j] = (x & 1).float()
+    esn0 = 3.0 + 10.0 * np.log10(1.0 / 4.0)
+    gain = 1.0 / np.sqrt(0.5 / 10.0 ** (esn0 / 10.0))
+    noise = torch.randn((nframes, T, 4), generator=g, device=device, dtype=torch.float32)
+    v = 127.5 + 32.0 * ((hard * 2.0 - 1.0) * gain + noise)
+    sym = v.to(torch.int32).clamp_(0, 255).to(torch.uint8)  # C truncation then clip
+    return sym.reshape(nframes, 4 * T).contiguous()
+
+
+def cpu_baseline(O, sym_host, framebits, want_seconds=10.0):
+    """AVX2 port on the host: 1 pinned thread (the x10 target's denominator) and all cores."""
+    n = sym_host.shape[0]
+    ncpu = len(os.sched_getaffinity(0))
+    avx2 = O.has_avx2()
+    # warm-up + reference output for the parity check
+    t0 = time.perf_counter()
+    ref = O.decode_batch(framebits, sym_host, nthreads=ncpu, avx2=avx2)
+    t_all = time.perf_counter() - t0
+    # single thread on a bounded sample sized for ~want_seconds
+    t0 = time.perf_counter()
+    O.decode_batch(framebits, sym_host[:2048], nthreads=1, avx2=avx2)
+    per_frame = (time.perf_counter() - t0) / 2048
+    ns = int(min(n, max(2048, want_seconds / per_frame)))
+    reps = max(1, int(round(want_seconds / (per_frame * ns))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        O.decode_batch(framebits, sym_host[:ns], nthreads=1, avx2=avx2)
+    t1 = time.perf_counter() - t0
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    base = {
+        "value": round(ns * reps * framebits / t1 / 1e6, 2),
+        "unit": "Mbit/s",
+        "cores": 1,
+        "kind": "port",
+        "impl": "oracle/vit_avx2.c (own AVX2 port)" if avx2 else "oracle/vit_oracle.c (scalar)",
+        "sample": "%d FIC frames x %d passes, 1 thread (%.1f s)" % (ns, reps, t1),
+        "all_cores": {"value": round(n * framebits / t_all / 1e6, 2), "cores": ncpu,
+                      "sample": "%d frames, 1 pass" % n},
+        "cpu": model,
+    }
+    return base, ref
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=65536, help="FIC frames per GPU per step")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 wave-per-frame, 2 packed")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("VITERBI_AMD_DEVICE", str(local_rank))
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    V = _vitpkg.load_package()
+    assert V.device_count() >= 1, "libviterbi.so sees no gfx950 device: " + V.last_error()
+    V.initialize()
+    V.set_kernel(args.kernel)
+
+    n = args.frames
+    d_sym = make_frames(n, FRAMEBITS, seed=1234 + rank, device=dev)
+    d_out = torch.zeros((n, FRAMEBITS // 8), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        V.decode_batch_dev(d_sym, d_out, FRAMEBITS, n)  # enqueues on torch's current stream
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record()
+        step()
+        b.record()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))  # HIP events on the launch stream
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    result = None
+    if rank == 0:
+        total_bits = float(world) * n * FRAMEBITS * args.steps
+        alg_bytes = n * (4 * (FRAMEBITS + TAIL) + FRAMEBITS // 8)  # 3192 B per FIC frame
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        result = {
+            "metric": "decoded Mbit/s per GPU on batched 768-bit DAB FIC frames; bit-exact vs AVX2 ref",
+            "value": round(total_bits / dt / 1e6, 1),
+            "unit": "Mbit/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "batch=65536 FIC frames (768 bit, 3096 soft symbols u8) per GPU, "
+                                   "resident in HBM; Eb/N0=3 dB reference-style noise",
+                       "frames_per_gpu": n, "framebits": FRAMEBITS, "kernel": args.kernel,
+                       "sharding": "independent shards per rank, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(traffic_file):
+            try:
+                with open(traffic_file) as f:
+                    result["roofline"]["traffic"] = json.load(f).get("hbm_bytes_per_launch")
+            except (OSError, ValueError):
+                pass
+        if world == 1 and not args.no_cpu:
+            O = _vitpkg.load_oracle()  # checker + timed CPU baseline only
+            sym_host = d_sym.cpu().numpy()
+            base, ref = cpu_baseline(O, sym_host, FRAMEBITS)
+            got = d_out.cpu().numpy()
+            bad = int((got != ref).any(axis=1).sum())
+            result["cpu_baseline"] = base
+            result["parity"] = {"frames_checked": n, "frames_differing": bad, "bit_exact": bad == 0}
+            result["speedup_vs_cpu_1thread"] = round(result["value"] / base["value"], 1)
+            if bad:
+                result["value"] = 0.0  # a fast kernel with wrong results is not a result
+        print(json.dumps(result), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

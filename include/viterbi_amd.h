@@ -1,0 +1,136 @@
+/*
+ * viterbi_amd.h -- C ABI of libviterbi.so, the MI355X (gfx950) drop-in for the
+ * compute path of Drehrumbum/viterbi.dll.
+ *
+ * Part 1 are the five exports of the reference's viterbi.def:4-8, same names,
+ * argument meaning and return values, so a caller that binds viterbi.dll
+ * (QIRX via P/Invoke, viterbi-benchmark.cpp:201-229 via GetProcAddress) binds
+ * this library unchanged (SysV x86-64 instead of Win64).  Part 2 is the build's
+ * own batched, device-resident extension: one 96-byte call cannot feed a GPU,
+ * so the throughput path takes many frames per call.
+ *
+ * All entry points are thread-safe.  No entry point ever computes on the CPU:
+ * when no HIP device is usable they return the error codes below.
+ */
+#ifndef VITERBI_AMD_H
+#define VITERBI_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------ *
+ * Part 1 -- drop-in exports (reference: viterbi.def:4-8)
+ * ------------------------------------------------------------------------ */
+
+/* Replaces `deconvolve` (deconvolve.cpp:551-554, typedef DECON viterbi.h:113;
+ * caller's view viterbi-benchmark.cpp:72-73).
+ *   framebits : decoded bits per frame, even, <= 9216 (deconvolve.cpp:126-127)
+ *   symbols   : 4*(framebits+6) soft symbols, one per u32, low byte used
+ *               (0 = strong "0", 255 = strong "1"; deconvolve.cpp:141-165)
+ *   unused    : ignored, like the reference's `inputLength`
+ *   decodedBits: receives (framebits+7)/8 bytes, MSB first
+ * Returns 0 on success, 1 on any failure ("save mode" value of
+ * viterbi_helpers.asm:184-186): bad arguments, no GPU, HIP error.
+ * framebits == 0 returns 0 without touching memory (C path behaviour). */
+int deconvolve(unsigned int framebits, unsigned int *symbols, int unused,
+               unsigned char *decodedBits);
+
+/* Replaces `initialize` (dllmain.cpp:156-160): re-reads the environment
+ * (VITERBI_AMD_DEVICE), clears the fault state; cheap, idempotent; returns
+ * non-zero (true). */
+unsigned char initialize(void);
+
+/* Replaces `RScheckSuperframe` (rschecksf.cpp:65-93).  RS(120,110) over
+ * GF(2^8)/0x11D on the RSDims columns of p[120*RSDims]; corrected first 110
+ * rows go to outVector[110*RSDims].  Returns the summed root counts, or -1 at
+ * the first uncorrectable column; that column and all later ones are left
+ * unwritten in outVector.  startIx is ignored (rschecksf.cpp:69).
+ * Also -1 on bad arguments / no GPU / HIP error (see vit_last_error()). */
+int RScheckSuperframe(unsigned char *p, int startIx, unsigned int RSDims,
+                      unsigned char *outVector);
+/* BASELINE.json spells it with a capital C; same function. */
+int RSCheckSuperframe(unsigned char *p, int startIx, unsigned int RSDims,
+                      unsigned char *outVector);
+
+/* Replaces `GetCPUCaps` (viterbi_helpers.asm:48-157, bit masks
+ * getcpucaps.h:27-38).  There is no x86 dispatch here: returns 0 when no
+ * usable GPU was found, otherwise VIT_CAPS_GFX950 | number of CUs << 8. */
+int GetCPUCaps(void);
+#define VIT_CAPS_GFX950 0x1
+
+/* Replaces `WakeUpYMM` (dllmain.cpp:54-56 / viterbi_helpers.asm:160-176): a
+ * warm-up hook.  Here it creates the calling thread's HIP stream and staging
+ * buffers so the first deconvolve() does not pay for them. */
+void WakeUpYMM(void);
+
+/* ------------------------------------------------------------------------ *
+ * Part 2 -- batched extension (not in the reference)
+ * ------------------------------------------------------------------------ */
+
+#define VIT_OK 0
+#define VIT_ERR_ARG 1
+#define VIT_ERR_NO_DEVICE 2
+#define VIT_ERR_HIP 3
+
+/* Last error text of the calling thread ("" if none). */
+const char *vit_last_error(void);
+/* Number of usable gfx950 devices (0 = none). */
+int vit_device_count(void);
+
+/* Frame descriptor for variable-length batches.
+ * sym_offset: byte offset of the frame's first soft symbol in the u8 symbol
+ * buffer, multiple of 4; the frame owns 4*(framebits+6) bytes from there.
+ * out_offset: byte offset of its framebits/8 output bytes. */
+typedef struct vit_frame_desc {
+    uint64_t sym_offset;
+    uint64_t out_offset;
+    uint32_t framebits; /* even, multiple of 8, <= 9216 */
+    uint32_t reserved;
+} vit_frame_desc;
+
+/* Device format of the soft symbols: one byte per symbol (the low byte of the
+ * reference's u32), frames back to back: frame f at f*4*(framebits+6).
+ * Decoded output: frame f at f*(framebits/8).
+ * All *_dev calls take DEVICE pointers and enqueue on `stream` (a hipStream_t,
+ * NULL = default stream) without synchronising. */
+int vit_decode_batch_dev(const uint8_t *d_symbols_u8, uint8_t *d_decoded,
+                         uint32_t framebits, int64_t nframes, void *stream);
+/* Same, symbols still in the reference ABI format (u32 per symbol); the
+ * u32->u8 narrowing runs on the device into an internal scratch buffer. */
+int vit_decode_batch_dev_u32(const uint32_t *d_symbols_u32, uint8_t *d_decoded,
+                             uint32_t framebits, int64_t nframes, void *stream);
+/* Variable-length batch; d_desc is a DEVICE array of nframes descriptors,
+ * max_framebits the largest framebits in it (host-known). */
+int vit_decode_varlen_dev(const uint8_t *d_symbols_u8, uint8_t *d_decoded,
+                          const vit_frame_desc *d_desc, int64_t nframes,
+                          uint32_t max_framebits, void *stream);
+/* u32 -> u8 narrowing of nsym symbols on the device (ingest stage). */
+int vit_pack_symbols_dev(const uint32_t *d_symbols_u32, uint8_t *d_symbols_u8,
+                         int64_t nsym, void *stream);
+
+/* Host-buffer convenience: H2D, decode, D2H, synchronous. */
+int vit_decode_batch_host(const uint8_t *h_symbols_u8, uint8_t *h_decoded,
+                          uint32_t framebits, int64_t nframes);
+
+/* Batched RScheckSuperframe: nsf superframes of 120*RSDims bytes each (device),
+ * outputs 110*RSDims bytes each; d_ret[s] receives what RScheckSuperframe
+ * would return for superframe s.  Output columns at and after the first
+ * uncorrectable column of a superframe are left untouched. */
+int vit_rs_batch_dev(const uint8_t *d_p, uint8_t *d_out, int32_t *d_ret,
+                     uint32_t RSDims, int64_t nsf, void *stream);
+int vit_rs_batch_host(const uint8_t *h_p, uint8_t *h_out, int32_t *h_ret,
+                      uint32_t RSDims, int64_t nsf);
+
+/* Kernel selection for experiments/tests: 0 = auto, 1 = wave-per-frame
+ * reference kernel, 2 = packed 4-frames-per-wave kernel.  Returns the old
+ * value.  Affects later vit_decode_* calls of the whole process. */
+int vit_set_kernel(int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITERBI_AMD_H */

@@ -1,0 +1,82 @@
+/*
+ * oracle/vit_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement of the reference's `deconvolve` + `RScheckSuperframe` hot
+ * path (Drehrumbum/viterbi.dll @ 2024_10_08).  Nothing under oracle/ is part
+ * of the shipped product: only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it, and only as the checker / the timed CPU
+ * baseline.  The product path (viterbi.dll_amd/csrc) never links or calls it.
+ *
+ * Pinning status: the reference cannot be compiled in this image without
+ * writing stand-ins for <windows.h>/<psapi.h> and restating const.asm (MASM),
+ * so there is no oracle/_ref build.  The oracle is pinned by the known-answer
+ * vectors recorded in SURVEY.md section 8c (outputs of the compiled reference
+ * taken during the survey) -- see tests/golden/ and tests/test_oracle_kat.py.
+ */
+#ifndef VIT_ORACLE_H
+#define VIT_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- Viterbi K=7 r=1/4 ---------------------------------------------------- */
+
+/* Scalar restatement; symbols in the reference ABI (one u32 per soft symbol,
+ * low byte used).  Returns 0.  ge_threshold!=0 selects the MASM twins'
+ * `>=150` renormalise test instead of the C path's `>150`. */
+int vo_deconvolve(unsigned framebits, const uint32_t *symbols, int unused,
+                  unsigned char *out);
+int vo_deconvolve_opt(unsigned framebits, const uint32_t *symbols,
+                      unsigned char *out, int ge_threshold);
+/* Same decoder over the build's device format: one byte per soft symbol. */
+int vo_deconvolve_u8(unsigned framebits, const uint8_t *symbols,
+                     unsigned char *out);
+/* Batch helpers (frames contiguous; u8 symbols, 4*(framebits+6) per frame;
+ * framebits/8 output bytes per frame).  nthreads<=1 -> serial. */
+int vo_decode_batch_u8(unsigned framebits, const uint8_t *symbols,
+                       unsigned char *out, long nframes, int nthreads);
+
+/* Hand-written AVX2 port of the same specification (own design), used as the
+ * timed CPU baseline.  Returns -1 when the host lacks AVX2. */
+int vo_has_avx2(void);
+int vo_deconvolve_avx2_u8(unsigned framebits, const uint8_t *symbols,
+                          unsigned char *out);
+int vo_decode_batch_avx2_u8(unsigned framebits, const uint8_t *symbols,
+                            unsigned char *out, long nframes, int nthreads);
+
+/* ---- helpers for building test vectors ----------------------------------- */
+
+/* DAB mother code encoder (polys 109,79,83,109; 6 zero tail bits).  bits: one
+ * bit per byte (0/1), framebits of them.  hard: 4*(framebits+6) bytes 0/1. */
+void vo_encode(unsigned framebits, const uint8_t *bits, uint8_t *hard);
+/* xorshift64 (13,7,17) stream used by the SURVEY KATs. */
+uint64_t vo_xorshift64(uint64_t *state);
+/* Fill n symbols with (xorshift64>>11)&255. */
+void vo_fill_uniform(uint64_t *state, uint8_t *sym, long n);
+/* Reference-style noisy frame: random bits -> mother code -> AWGN at
+ * ebn0_db, sample = 127.5 + 32*N(+-gain,1), clipped 0..255; own seeded RNG.
+ * bits_out (framebits bytes 0/1) may be NULL. */
+void vo_make_noisy_frame(uint64_t *state, unsigned framebits, double ebn0_db,
+                         uint8_t *sym, uint8_t *bits_out);
+uint64_t vo_fnv1a64(const uint8_t *p, long n);
+
+/* ---- Reed-Solomon RS(120,110) over GF(2^8)/0x11D -------------------------- */
+
+/* tables: ato_mod[768], index_of[256] as CreateLookupTables builds them */
+void vo_rs_tables(uint8_t *ato_mod, uint8_t *index_of);
+/* one codeword, data[120] widened to u32 like the reference; returns number of
+ * roots, 0 for a clean word, -1 uncorrectable; patches data in place. */
+int vo_decode_rs(uint32_t *data);
+int vo_rs_check_superframe(const unsigned char *p, int startIx,
+                           unsigned RSDims, unsigned char *outVector);
+/* systematic encoder for test data: msg[110] -> cw[120] (generator
+ * prod_{i=0..9}(x + alpha^i), shortened RS(255,245)). */
+void vo_rs_encode(const uint8_t *msg, uint8_t *cw);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

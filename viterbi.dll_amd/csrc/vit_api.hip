@@ -1,0 +1,374 @@
+// vit_api.hip -- the C ABI of libviterbi.so (include/viterbi_amd.h).
+//
+// Host side of the drop-in: argument validation, per-thread HIP stream and
+// staging buffers, the fault ("save mode") flag, kernel selection.  No decode
+// arithmetic happens on the host; when no gfx950 device is usable every entry
+// point fails loudly with the documented error value.
+//
+// Reference boundary being replaced: viterbi.def:4-8, deconvolve.cpp:551-554,
+// rschecksf.cpp:65-93, dllmain.cpp:156-160, setupdll.cpp:195-270 (dispatcher),
+// exc_handler.cpp:150-249 (fault -> save mode).
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "vit_internal.h"
+
+namespace {
+
+thread_local char t_err[256] = "";
+void set_err(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_err, sizeof t_err, fmt, ap);
+    va_end(ap);
+    if (getenv("VITERBI_AMD_VERBOSE")) fprintf(stderr, "[libviterbi] %s\n", t_err);
+}
+
+// ---- process-wide state (written at init only, like deconJumpTarget) -------
+std::once_flag g_once;
+int g_ndev = 0;           // usable gfx950 devices
+int g_device = -1;        // selected device
+int g_cus = 0;
+std::atomic<int> g_fault{0};   // reference: exceptCounter / decon_savemode
+std::atomic<int> g_kernel{0};  // 0 auto, 1 wave, 2 packed
+
+void probe_devices() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        g_ndev = 0;
+        g_device = -1;
+        return;
+    }
+    int want = 0;
+    if (const char* e = getenv("VITERBI_AMD_DEVICE")) want = atoi(e);
+    int usable = 0, chosen = -1, first = -1, first_cus = 0;
+    for (int d = 0; d < n; d++) {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, d) != hipSuccess) continue;
+        if (strncmp(pr.gcnArchName, "gfx950", 6) != 0) continue;  // kernels exist for gfx950 only
+        if (first < 0) { first = d; first_cus = pr.multiProcessorCount; }
+        if (usable == want) { chosen = d; g_cus = pr.multiProcessorCount; }
+        usable++;
+    }
+    if (chosen < 0) { chosen = first; g_cus = first_cus; }
+    g_ndev = usable;
+    g_device = chosen;
+}
+void ensure_init() { std::call_once(g_once, probe_devices); }
+
+// ---- per-thread context: stream + staging (README.md:56: callers are threads) ----
+struct ThreadCtx {
+    hipStream_t stream = nullptr;
+    void* h_pin = nullptr;   size_t h_cap = 0;   // pinned host staging
+    void* d_in = nullptr;    size_t din_cap = 0; // device input (u32 or u8 / RS block)
+    void* d_sym8 = nullptr;  size_t d8_cap = 0;  // packed symbols
+    void* d_out = nullptr;   size_t dout_cap = 0;
+    void* d_ret = nullptr;   size_t dret_cap = 0;
+    bool ready = false;
+    ~ThreadCtx() {
+        if (!ready) return;
+        // process teardown may already have destroyed the runtime: ignore errors
+        if (h_pin) (void)hipHostFree(h_pin);
+        if (d_in) (void)hipFree(d_in);
+        if (d_sym8) (void)hipFree(d_sym8);
+        if (d_out) (void)hipFree(d_out);
+        if (d_ret) (void)hipFree(d_ret);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+thread_local ThreadCtx t_ctx;
+
+#define HIPCHK(call)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            set_err("%s failed: %s", #call, hipGetErrorString(e_));                        \
+            return VIT_ERR_HIP;                                                            \
+        }                                                                                  \
+    } while (0)
+
+int ctx_prepare() {
+    ensure_init();
+    if (g_device < 0) {
+        set_err("no usable gfx950 (MI355X) HIP device; libviterbi has no CPU path");
+        return VIT_ERR_NO_DEVICE;
+    }
+    HIPCHK(hipSetDevice(g_device));
+    if (!t_ctx.ready) {
+        HIPCHK(hipStreamCreateWithFlags(&t_ctx.stream, hipStreamNonBlocking));
+        t_ctx.ready = true;
+    }
+    return VIT_OK;
+}
+int grow_dev(void** p, size_t* cap, size_t need) {
+    if (*cap >= need) return VIT_OK;
+    if (*p) HIPCHK(hipFree(*p));
+    *p = nullptr; *cap = 0;
+    size_t sz = need < 65536 ? 65536 : need + need / 4;
+    HIPCHK(hipMalloc(p, sz));
+    *cap = sz;
+    return VIT_OK;
+}
+int grow_pin(size_t need) {
+    if (t_ctx.h_cap >= need) return VIT_OK;
+    if (t_ctx.h_pin) HIPCHK(hipHostFree(t_ctx.h_pin));
+    t_ctx.h_pin = nullptr; t_ctx.h_cap = 0;
+    size_t sz = need < 65536 ? 65536 : need + need / 4;
+    HIPCHK(hipHostMalloc(&t_ctx.h_pin, sz, hipHostMallocDefault));
+    t_ctx.h_cap = sz;
+    return VIT_OK;
+}
+
+bool valid_framebits(uint32_t fb) { return fb <= VIT_MAX_FRAMEBITS && (fb & 1u) == 0; }
+
+// the analogue of setupdll.cpp:195-270's dispatcher: choose the kernel for a batch
+int launch_decode(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_desc* d_desc, uint32_t framebits,
+                  uint32_t max_framebits, int64_t nframes, hipStream_t s) {
+    const int k = g_kernel.load();
+    const bool pk_ok = (max_framebits % 8u) == 0 && (!d_desc ? (framebits % 8u) == 0 : true) &&
+                       vit_pk_supported(max_framebits);
+    const bool use_pk = (k == 2) ? pk_ok : (k == 1 ? false : pk_ok);
+    if (k == 2 && !pk_ok) {
+        set_err("packed kernel does not support framebits=%u", max_framebits);
+        return VIT_ERR_ARG;
+    }
+    hipError_t e = use_pk ? vit_launch_pk(d_sym, d_out, d_desc, framebits, max_framebits, nframes, s)
+                          : vit_launch_wave(d_sym, d_out, d_desc, framebits, max_framebits, nframes, s);
+    if (e != hipSuccess) {
+        set_err("kernel launch failed: %s", hipGetErrorString(e));
+        return VIT_ERR_HIP;
+    }
+    return VIT_OK;
+}
+
+int hip_device_ready() {
+    ensure_init();
+    if (g_device < 0) {
+        set_err("no usable gfx950 (MI355X) HIP device; libviterbi has no CPU path");
+        return VIT_ERR_NO_DEVICE;
+    }
+    return VIT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vit_last_error(void) { return t_err; }
+
+int vit_device_count(void) {
+    ensure_init();
+    return g_ndev;
+}
+
+int vit_set_kernel(int which) {
+    if (which < 0 || which > 2) which = 0;
+    return g_kernel.exchange(which);
+}
+
+unsigned char initialize(void) {
+    // dllmain.cpp:156-160: clear the fault counter and re-run the (idempotent) set-up.
+    g_fault.store(0);
+    ensure_init();
+    (void)hipGetLastError();
+    return 1;
+}
+
+int GetCPUCaps(void) {
+    ensure_init();
+    if (g_device < 0) return 0;
+    return VIT_CAPS_GFX950 | (g_cus << 8);
+}
+
+void WakeUpYMM(void) {
+    if (ctx_prepare() != VIT_OK) return;
+    (void)grow_pin(65536);
+    (void)grow_dev(&t_ctx.d_in, &t_ctx.din_cap, 65536);
+    (void)grow_dev(&t_ctx.d_sym8, &t_ctx.d8_cap, 65536);
+    (void)grow_dev(&t_ctx.d_out, &t_ctx.dout_cap, 65536);
+}
+
+int vit_pack_symbols_dev(const uint32_t* d_symbols_u32, uint8_t* d_symbols_u8, int64_t nsym, void* stream) {
+    if (hip_device_ready() != VIT_OK) return VIT_ERR_NO_DEVICE;
+    if (nsym < 0 || (nsym > 0 && (!d_symbols_u32 || !d_symbols_u8))) {
+        set_err("vit_pack_symbols_dev: bad arguments");
+        return VIT_ERR_ARG;
+    }
+    hipError_t e = vit_launch_pack(d_symbols_u32, d_symbols_u8, nsym, (hipStream_t)stream);
+    if (e != hipSuccess) { set_err("pack launch failed: %s", hipGetErrorString(e)); return VIT_ERR_HIP; }
+    return VIT_OK;
+}
+
+int vit_decode_batch_dev(const uint8_t* d_symbols_u8, uint8_t* d_decoded, uint32_t framebits, int64_t nframes,
+                         void* stream) {
+    if (hip_device_ready() != VIT_OK) return VIT_ERR_NO_DEVICE;
+    if (!valid_framebits(framebits) || nframes < 0 || (nframes > 0 && framebits > 0 && (!d_symbols_u8 || !d_decoded))) {
+        set_err("vit_decode_batch_dev: bad arguments (framebits=%u nframes=%lld)", framebits, (long long)nframes);
+        return VIT_ERR_ARG;
+    }
+    if (framebits == 0 || nframes == 0) return VIT_OK;
+    return launch_decode(d_symbols_u8, d_decoded, nullptr, framebits, framebits, nframes, (hipStream_t)stream);
+}
+
+int vit_decode_batch_dev_u32(const uint32_t* d_symbols_u32, uint8_t* d_decoded, uint32_t framebits,
+                             int64_t nframes, void* stream) {
+    if (hip_device_ready() != VIT_OK) return VIT_ERR_NO_DEVICE;
+    if (!valid_framebits(framebits) || nframes < 0 || (nframes > 0 && framebits > 0 && (!d_symbols_u32 || !d_decoded))) {
+        set_err("vit_decode_batch_dev_u32: bad arguments");
+        return VIT_ERR_ARG;
+    }
+    if (framebits == 0 || nframes == 0) return VIT_OK;
+    int rc = ctx_prepare();
+    if (rc != VIT_OK) return rc;
+    const size_t nsym = (size_t)nframes * 4u * (framebits + VIT_TAIL);
+    rc = grow_dev(&t_ctx.d_sym8, &t_ctx.d8_cap, nsym);  // may synchronise the device (hipMalloc)
+    if (rc != VIT_OK) return rc;
+    hipError_t e = vit_launch_pack(d_symbols_u32, (uint8_t*)t_ctx.d_sym8, (int64_t)nsym, (hipStream_t)stream);
+    if (e != hipSuccess) { set_err("pack launch failed: %s", hipGetErrorString(e)); return VIT_ERR_HIP; }
+    return launch_decode((const uint8_t*)t_ctx.d_sym8, d_decoded, nullptr, framebits, framebits, nframes,
+                         (hipStream_t)stream);
+}
+
+int vit_decode_varlen_dev(const uint8_t* d_symbols_u8, uint8_t* d_decoded, const vit_frame_desc* d_desc,
+                          int64_t nframes, uint32_t max_framebits, void* stream) {
+    if (hip_device_ready() != VIT_OK) return VIT_ERR_NO_DEVICE;
+    if (!valid_framebits(max_framebits) || nframes < 0 ||
+        (nframes > 0 && (!d_symbols_u8 || !d_decoded || !d_desc))) {
+        set_err("vit_decode_varlen_dev: bad arguments");
+        return VIT_ERR_ARG;
+    }
+    if (nframes == 0 || max_framebits == 0) return VIT_OK;
+    return launch_decode(d_symbols_u8, d_decoded, d_desc, 0, max_framebits, nframes, (hipStream_t)stream);
+}
+
+int vit_decode_batch_host(const uint8_t* h_symbols_u8, uint8_t* h_decoded, uint32_t framebits, int64_t nframes) {
+    if (!valid_framebits(framebits) || nframes < 0 || (nframes > 0 && framebits > 0 && (!h_symbols_u8 || !h_decoded))) {
+        set_err("vit_decode_batch_host: bad arguments");
+        return VIT_ERR_ARG;
+    }
+    if (framebits == 0 || nframes == 0) return VIT_OK;
+    int rc = ctx_prepare();
+    if (rc != VIT_OK) return rc;
+    const size_t in_sz = (size_t)nframes * 4u * (framebits + VIT_TAIL);
+    const size_t out_sz = (size_t)nframes * ((framebits + 7u) >> 3);
+    if ((rc = grow_dev(&t_ctx.d_sym8, &t_ctx.d8_cap, in_sz)) != VIT_OK) return rc;
+    if ((rc = grow_dev(&t_ctx.d_out, &t_ctx.dout_cap, out_sz)) != VIT_OK) return rc;
+    HIPCHK(hipMemcpyAsync(t_ctx.d_sym8, h_symbols_u8, in_sz, hipMemcpyHostToDevice, t_ctx.stream));
+    rc = launch_decode((const uint8_t*)t_ctx.d_sym8, (uint8_t*)t_ctx.d_out, nullptr, framebits, framebits, nframes,
+                       t_ctx.stream);
+    if (rc != VIT_OK) return rc;
+    HIPCHK(hipMemcpyAsync(h_decoded, t_ctx.d_out, out_sz, hipMemcpyDeviceToHost, t_ctx.stream));
+    HIPCHK(hipStreamSynchronize(t_ctx.stream));
+    return VIT_OK;
+}
+
+int deconvolve(unsigned int framebits, unsigned int* symbols, int unused, unsigned char* decodedBits) {
+    (void)unused;  // never read by the reference either (deconvolve.cpp:447-526)
+    if (framebits == 0) return 0;  // C path: loop count 0, no memory touched
+    if (g_fault.load()) return 1;  // save mode until initialize() (exc_handler.cpp:214,243)
+    if (!symbols || !decodedBits || !valid_framebits(framebits)) {
+        set_err("deconvolve: bad arguments (framebits=%u)", framebits);
+        return 1;
+    }
+    if (ctx_prepare() != VIT_OK) return 1;
+    const size_t nsym = 4u * ((size_t)framebits + VIT_TAIL);
+    const size_t out_sz = (framebits + 7u) >> 3;
+    int rc;
+    if ((rc = grow_pin(nsym * 4 + out_sz + 64)) != VIT_OK || (rc = grow_dev(&t_ctx.d_in, &t_ctx.din_cap, nsym * 4)) != VIT_OK ||
+        (rc = grow_dev(&t_ctx.d_sym8, &t_ctx.d8_cap, nsym)) != VIT_OK ||
+        (rc = grow_dev(&t_ctx.d_out, &t_ctx.dout_cap, out_sz)) != VIT_OK) {
+        g_fault.store(1);
+        return 1;
+    }
+    auto fail = [&](const char* what, hipError_t e) {
+        set_err("deconvolve: %s: %s", what, hipGetErrorString(e));
+        g_fault.store(1);
+        return 1;
+    };
+    hipError_t e;
+    unsigned char* h_out = (unsigned char*)t_ctx.h_pin + nsym * 4;
+    memcpy(t_ctx.h_pin, symbols, nsym * 4);
+    if ((e = hipMemcpyAsync(t_ctx.d_in, t_ctx.h_pin, nsym * 4, hipMemcpyHostToDevice, t_ctx.stream)) != hipSuccess)
+        return fail("H2D", e);
+    if ((e = vit_launch_pack((const uint32_t*)t_ctx.d_in, (uint8_t*)t_ctx.d_sym8, (int64_t)nsym, t_ctx.stream)) != hipSuccess)
+        return fail("pack", e);
+    if (launch_decode((const uint8_t*)t_ctx.d_sym8, (uint8_t*)t_ctx.d_out, nullptr, framebits, framebits, 1,
+                      t_ctx.stream) != VIT_OK) {
+        g_fault.store(1);
+        return 1;
+    }
+    if ((e = hipMemcpyAsync(h_out, t_ctx.d_out, out_sz, hipMemcpyDeviceToHost, t_ctx.stream)) != hipSuccess)
+        return fail("D2H", e);
+    if ((e = hipStreamSynchronize(t_ctx.stream)) != hipSuccess) return fail("sync", e);
+    memcpy(decodedBits, h_out, out_sz);
+    return 0;
+}
+
+int vit_rs_batch_dev(const uint8_t* d_p, uint8_t* d_out, int32_t* d_ret, uint32_t RSDims, int64_t nsf, void* stream) {
+    if (hip_device_ready() != VIT_OK) return VIT_ERR_NO_DEVICE;
+    if (nsf < 0 || (nsf > 0 && RSDims > 0 && (!d_p || !d_out || !d_ret)) || RSDims > 65535u) {
+        set_err("vit_rs_batch_dev: bad arguments");
+        return VIT_ERR_ARG;
+    }
+    if (nsf == 0) return VIT_OK;
+    if (RSDims == 0) {  // zero columns: the reference's loop does not run, returns 0
+        hipError_t e0 = hipMemsetAsync(d_ret, 0, (size_t)nsf * sizeof(int32_t), (hipStream_t)stream);
+        if (e0 != hipSuccess) { set_err("memset: %s", hipGetErrorString(e0)); return VIT_ERR_HIP; }
+        return VIT_OK;
+    }
+    hipError_t e = rs_launch(d_p, d_out, d_ret, RSDims, nsf, (hipStream_t)stream);
+    if (e != hipSuccess) { set_err("rs launch failed: %s", hipGetErrorString(e)); return VIT_ERR_HIP; }
+    return VIT_OK;
+}
+
+int vit_rs_batch_host(const uint8_t* h_p, uint8_t* h_out, int32_t* h_ret, uint32_t RSDims, int64_t nsf) {
+    if (nsf < 0 || RSDims > 65535u || (nsf > 0 && (!h_ret || (RSDims > 0 && (!h_p || !h_out))))) {
+        set_err("vit_rs_batch_host: bad arguments");
+        return VIT_ERR_ARG;
+    }
+    if (nsf == 0) return VIT_OK;
+    if (RSDims == 0) { memset(h_ret, 0, (size_t)nsf * sizeof(int32_t)); return VIT_OK; }
+    int rc = ctx_prepare();
+    if (rc != VIT_OK) return rc;
+    const size_t in_sz = (size_t)nsf * 120u * RSDims, out_sz = (size_t)nsf * 110u * RSDims;
+    if ((rc = grow_dev(&t_ctx.d_in, &t_ctx.din_cap, in_sz)) != VIT_OK) return rc;
+    if ((rc = grow_dev(&t_ctx.d_out, &t_ctx.dout_cap, out_sz)) != VIT_OK) return rc;
+    if ((rc = grow_dev(&t_ctx.d_ret, &t_ctx.dret_cap, (size_t)nsf * 4)) != VIT_OK) return rc;
+    HIPCHK(hipMemcpyAsync(t_ctx.d_in, h_p, in_sz, hipMemcpyHostToDevice, t_ctx.stream));
+    // columns at/after the first failure must keep the caller's bytes: seed the device copy
+    HIPCHK(hipMemcpyAsync(t_ctx.d_out, h_out, out_sz, hipMemcpyHostToDevice, t_ctx.stream));
+    hipError_t e = rs_launch((const uint8_t*)t_ctx.d_in, (uint8_t*)t_ctx.d_out, (int32_t*)t_ctx.d_ret, RSDims, nsf,
+                             t_ctx.stream);
+    if (e != hipSuccess) { set_err("rs launch failed: %s", hipGetErrorString(e)); return VIT_ERR_HIP; }
+    HIPCHK(hipMemcpyAsync(h_out, t_ctx.d_out, out_sz, hipMemcpyDeviceToHost, t_ctx.stream));
+    HIPCHK(hipMemcpyAsync(h_ret, t_ctx.d_ret, (size_t)nsf * 4, hipMemcpyDeviceToHost, t_ctx.stream));
+    HIPCHK(hipStreamSynchronize(t_ctx.stream));
+    return VIT_OK;
+}
+
+int RScheckSuperframe(unsigned char* p, int startIx, unsigned int RSDims, unsigned char* outVector) {
+    (void)startIx;  // rschecksf.cpp:69
+    if (RSDims == 0) return 0;
+    if (g_fault.load()) return -1;
+    if (!p || !outVector) {
+        set_err("RScheckSuperframe: NULL buffer");
+        return -1;
+    }
+    int32_t ret = -1;
+    if (vit_rs_batch_host(p, outVector, &ret, RSDims, 1) != VIT_OK) {
+        g_fault.store(1);
+        return -1;
+    }
+    return ret;
+}
+
+int RSCheckSuperframe(unsigned char* p, int startIx, unsigned int RSDims, unsigned char* outVector) {
+    return RScheckSuperframe(p, startIx, RSDims, outVector);
+}
+
+}  // extern "C"

@@ -1,0 +1,26 @@
+// vit_internal.h -- launchers shared between the kernel TUs and the C-ABI TU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "viterbi_amd.h"
+
+#define VIT_MAX_FRAMEBITS 9216u  // deconvolve.cpp:93,127 (384*24)
+#define VIT_TAIL 6u              // K-1 tail steps
+
+// Wave-per-frame kernel (lane = trellis state); any even framebits <= 9216.
+hipError_t vit_launch_wave(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_desc* d_desc,
+                           uint32_t framebits, uint32_t max_framebits, int64_t nframes,
+                           hipStream_t stream);
+// Packed kernel: 4 frames per wavefront, 2 states x 2 frames per lane register.
+// Needs framebits % 8 == 0 and 4 frames' decisions to fit the LDS budget.
+bool vit_pk_supported(uint32_t max_framebits);
+hipError_t vit_launch_pk(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_desc* d_desc,
+                         uint32_t framebits, uint32_t max_framebits, int64_t nframes,
+                         hipStream_t stream);
+// u32 -> u8 narrowing (low byte), the reference ABI's symbol format to the device format.
+hipError_t vit_launch_pack(const uint32_t* d_sym32, uint8_t* d_sym8, int64_t nsym,
+                           hipStream_t stream);
+// RS(120,110) superframe check, one lane per column.
+hipError_t rs_launch(const uint8_t* d_p, uint8_t* d_out, int32_t* d_ret, uint32_t rsdims,
+                     int64_t nsf, hipStream_t stream);

@@ -224,7 +224,7 @@ def test_rscheck_export(V, O, torch_cuda):
     rc, out = V.RScheckSuperframe(p, 0, rsdims)
     assert rc == 3 and not out.any()
     q = np.zeros(120 * rsdims, np.uint8)
-    q[[5 + rsdims * k for k in (1, 9, 20, 33, 47, 90)]] = [1, 2, 3, 4, 5, 6]  # 6 errors in column 5 -> -1
+    q[[5 + rsdims * k for k in (1, 9, 20, 33, 47, 90)]] = [7, 99, 3, 200, 5, 66]  # 6 errors in column 5 -> -1
     sentinel = np.full(110 * rsdims, 0x77, np.uint8)
     rc, out = V.RScheckSuperframe(q, 0, rsdims, sentinel.copy())
     rc_ref, out_ref = O.rs_check_superframe(q, rsdims, sentinel.copy())

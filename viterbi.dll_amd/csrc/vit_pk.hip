@@ -1,6 +1,348 @@
-// placeholder, replaced below
+// vit_pk.hip -- packed K=7 r=1/4 Viterbi decoder for gfx950: FOUR frames per
+// wavefront, no cross-lane traffic through LDS in the add-compare-select loop.
+//
+// Layout.  A wave owns frames F(p,h), p = lane>>5 ("pair"), h = 16-bit half of a
+// VGPR.  Within a pair, the 64 path metrics of a frame live in two registers x 32
+// lanes: register A holds the state with s5 = 0, register B the one with s5 = 1,
+// of the butterfly i = rol5(lane&31, t mod 5).  A butterfly therefore reads both
+// of its predecessors (i, i+32) from its own lane, and both survivors
+// (2i, 2i+1) stay in the lane.  After each step ONE register bit and ONE lane
+// bit swap roles (lane bit 4,3,2,1,0,4,... = 4 - t mod 5): v_permlane16_swap for
+// bit 4, masked DPP moves for bits 3..0.  The state <-> lane map rotates with
+// period 5, so the step body is unrolled 5-periodically (16 steps x 5 variants).
+//
+// Arithmetic.  Metrics are u16 lanes of v_pk_* instructions holding m + 0xFF00,
+// so `v_pk_add_u16 clamp` IS paddusb (saturation at 255).  The renormalisation
+// (`psubusb 63` when state 0 > 150, every second step) is `v_pk_sub_u16 clamp`
+// against 0xFF00 + {0,63}, which lands in a 0-based representation; the branch
+// metric table of the following (even) step carries the +0xFF00 back.  Decisions
+// are the sign bits of m0-m1 / m2-m3, shifted into two per-lane history registers
+// and stored to LDS every 16 steps (8 B/lane).
+//
+// Branch metrics.  Only 8 distinct (b0,b1,b2) mask triples exist, so a 16-step
+// pre-pass (lane = frame x step) computes the 8 pavgb-tree metrics with byte-wide
+// v_lerp_u8 and writes a (M, 63-M) table to LDS; an ACS lane reads its 8 bytes.
+//
+// Traceback.  Blocked and speculative: lane = (frame, block of BL steps); every
+// block is traced from state 0, then re-traced from the state its successor block
+// ended in until nothing changes.  The last block really starts in state 0
+// (tail-terminated), so the fixed point is exactly the serial chainback.
+//
+// Replaces, from scratch: decon_avx2 / Butterfly256 (deconvolve.cpp:334-387,
+// 514-526), Load8Syms256 (:219-228), Renormalize256 (:407-412), ChainBack
+// (:416-435), chainback.inc:18-41 and const.asm:19-63.
 #include "vit_internal.h"
-bool vit_pk_supported(uint32_t) { return false; }
-hipError_t vit_launch_pk(const uint8_t*, uint8_t*, const vit_frame_desc*, uint32_t, uint32_t, int64_t, hipStream_t) {
-    return hipErrorNotSupported;
+
+namespace {
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32;
+
+#define DEV __device__ __forceinline__
+
+DEV us2 U(u32 x) { return __builtin_bit_cast(us2, x); }
+DEV u32 W(us2 x) { return __builtin_bit_cast(u32, x); }
+DEV u32 avg4(u32 a, u32 b) { return __builtin_amdgcn_lerp(a, b, 0x01010101u); }  // pavgb x4
+
+constexpr int TAB_BYTES = 2048;  // 16 steps x 2 pairs x 8 triples x (M,MM) 8 B
+constexpr int DEC_BLOCK = 512;   // 16 steps of decisions: 64 lanes x 8 B
+constexpr u32 HI = 0xFF00FF00u;  // +0xFF00 in both halves
+constexpr int KW = 8;            // traceback bit words per lane (BL <= 256)
+
+struct Lanes {
+    u32 toff[5];  // LDS byte offset of this lane's (M,MM) entry for phase rho
+};
+
+// lane-bit <-> register-bit transpose on lane bit J: afterwards A holds the s5=0
+// member and B the s5=1 member of the next butterfly.
+template <int J>
+DEV void exchange(u32& A, u32& B, u32 N0, u32 N1, u32 lane) {
+    if constexpr (J == 4) {
+        // swap N0's odd rows with N1's even rows (rows = 16 lanes)
+        auto r = __builtin_amdgcn_permlane16_swap(N0, N1, false, false);
+        A = r[0];
+        B = r[1];
+    } else if constexpr (J == 3) {
+        A = __builtin_amdgcn_update_dpp(N0, N1, 0x128 /*row_ror:8*/, 0xF, 0xC, false);
+        B = __builtin_amdgcn_update_dpp(N1, N0, 0x128, 0xF, 0x3, false);
+    } else if constexpr (J == 2) {
+        A = __builtin_amdgcn_update_dpp(N0, N1, 0x114 /*row_shr:4*/, 0xF, 0xA, false);
+        B = __builtin_amdgcn_update_dpp(N1, N0, 0x104 /*row_shl:4*/, 0xF, 0x5, false);
+    } else if constexpr (J == 1) {
+        // DPP reads need the SOURCE lane active, so the moves run on all lanes and a select follows
+        const u32 pn1 = __builtin_amdgcn_update_dpp(0u, N1, 0x4E /*quad_perm:[2,3,0,1]*/, 0xF, 0xF, true);
+        const u32 pn0 = __builtin_amdgcn_update_dpp(0u, N0, 0x4E, 0xF, 0xF, true);
+        const bool hi = lane & 2u;
+        A = hi ? pn1 : N0;
+        B = hi ? N1 : pn0;
+    } else {
+        const u32 pn1 = __builtin_amdgcn_update_dpp(0u, N1, 0xB1 /*quad_perm:[1,0,3,2]*/, 0xF, 0xF, true);
+        const u32 pn0 = __builtin_amdgcn_update_dpp(0u, N0, 0xB1, 0xF, 0xF, true);
+        const bool hi = lane & 1u;
+        A = hi ? pn1 : N0;
+        B = hi ? N1 : pn0;
+    }
+}
+
+// One trellis step for 4 frames (deconvolve.cpp:352-374 in packed u16 form).
+template <int RHO, bool ODD>
+DEV void acs_step(u32& A, u32& B, u32& acc0, u32& acc1, uint2 mt, u32 lane) {
+    const us2 a = U(A), b = U(B), M = U(mt.x), MM = U(mt.y);
+    const us2 m0 = __builtin_elementwise_add_sat(a, M), m1 = __builtin_elementwise_add_sat(b, MM);
+    const us2 m2 = __builtin_elementwise_add_sat(a, MM), m3 = __builtin_elementwise_add_sat(b, M);
+    us2 n0 = __builtin_elementwise_min(m0, m1), n1 = __builtin_elementwise_min(m2, m3);
+    // sign(m0-m1) = 1  <=>  m0 < m1  <=>  decision bit 0 (tie -> decision 1)
+    const us2 x01 = m0 - m1, x23 = m2 - m3;
+    acc0 = (W(x01) & 0x80008000u) | W(U(acc0) >> (unsigned short)1);
+    acc1 = (W(x23) & 0x80008000u) | W(U(acc1) >> (unsigned short)1);
+    if constexpr (ODD) {
+        // Renormalize256: state 0 (lane 0 of the pair, register N0) > 150 -> psubusb 63
+        const u32 z = (u32)__builtin_amdgcn_ds_swizzle((int)W(n0), 0);  // lane 0 of each 32-lane group
+        const us2 over = __builtin_elementwise_sub_sat(U(z), U(0xFF96FF96u));  // > 0 iff metric > 150
+        const us2 K = __builtin_elementwise_min(over, U(0x00010001u)) * U(0x003F003Fu) + U(HI);
+        n0 = __builtin_elementwise_sub_sat(n0, K);  // -> 0-based representation
+        n1 = __builtin_elementwise_sub_sat(n1, K);
+    }
+    exchange<4 - RHO>(A, B, W(n0), W(n1), lane);
+}
+
+template <int V, int J>
+struct Steps {
+    static DEV void run(u32& A, u32& B, u32& acc0, u32& acc1, const char* tab, const Lanes& L, u32 lane) {
+        constexpr int RHO = (V + J) % 5;
+        const uint2 mt = *reinterpret_cast<const uint2*>(tab + L.toff[RHO] + J * 128);
+        acs_step<RHO, (J & 1) != 0>(A, B, acc0, acc1, mt, lane);
+        Steps<V, J + 1>::run(A, B, acc0, acc1, tab, L, lane);
+    }
+};
+template <int V>
+struct Steps<V, 16> {
+    static DEV void run(u32&, u32&, u32&, u32&, const char*, const Lanes&, u32) {}
+};
+
+// Pre-pass for 16 steps: lane = (tau = lane>>2, pair = (lane>>1)&1, half = lane&1).
+// s = the 4 soft symbols (bytes) of this lane's frame at step t0+tau.
+DEV void prepass(u32 s, char* tab, u32 lane, const u32 (&sel)[4]) {
+    // pavgb tree shared between the 8 mask triples c = b0 | b1<<1 | b2<<2:
+    // metric(c) = avg(avg(s0^B0, s1^B1), avg(s2^B2, s3^B0)) >> 2   (b3 = b0)
+    const u32 r0 = __builtin_amdgcn_perm(s, s, 0x00000000u) ^ 0xFF00FF00u;  // s0 ^ B0, byte pos = b0 + 2*b1
+    const u32 r1 = __builtin_amdgcn_perm(s, s, 0x01010101u) ^ 0xFFFF0000u;  // s1 ^ B1
+    const u32 r2 = __builtin_amdgcn_perm(s, s, 0x02020202u) ^ 0xFFFF0000u;  // s2 ^ B2, byte pos = b0 + 2*b2
+    const u32 r3 = __builtin_amdgcn_perm(s, s, 0x03030303u) ^ 0xFF00FF00u;  // s3 ^ B0
+    const u32 P = avg4(r0, r1), Q = avg4(r2, r3);
+    const u32 qlo = __builtin_amdgcn_perm(Q, Q, 0x01000100u);  // [Q(b0,b2=0)] aligned to P's (b0,b1)
+    const u32 qhi = __builtin_amdgcn_perm(Q, Q, 0x03020302u);  // b2 = 1
+    const u32 metlo = (avg4(P, qlo) >> 2) & 0x3F3F3F3Fu;  // c = 0..3
+    const u32 methi = (avg4(P, qhi) >> 2) & 0x3F3F3F3Fu;  // c = 4..7
+    const u32 mmlo = 0x3F3F3F3Fu - metlo, mmhi = 0x3F3F3F3Fu - methi;
+    // combine the two frames of the pair (partner = lane^1): half 0 builds c=0..3, half 1 c=4..7
+    const bool h = lane & 1u;
+    const u32 mine_met = h ? methi : metlo, mine_mm = h ? mmhi : mmlo;
+    const u32 send_met = h ? metlo : methi, send_mm = h ? mmlo : mmhi;
+    const u32 part_met = __builtin_amdgcn_update_dpp(0u, send_met, 0xB1, 0xF, 0xF, true);
+    const u32 part_mm = __builtin_amdgcn_update_dpp(0u, send_mm, 0xB1, 0xF, 0xF, true);
+    const u32 lo_met = h ? part_met : mine_met, hi_met = h ? mine_met : part_met;  // frame half 0 / half 1
+    const u32 lo_mm = h ? part_mm : mine_mm, hi_mm = h ? mine_mm : part_mm;
+    uint4 e0, e1;  // (M,MM) x 4 triples; sel[] also injects +0xFF00 on even steps
+    e0.x = __builtin_amdgcn_perm(hi_met, lo_met, sel[0]);
+    e0.y = __builtin_amdgcn_perm(hi_mm, lo_mm, sel[0]);
+    e0.z = __builtin_amdgcn_perm(hi_met, lo_met, sel[1]);
+    e0.w = __builtin_amdgcn_perm(hi_mm, lo_mm, sel[1]);
+    e1.x = __builtin_amdgcn_perm(hi_met, lo_met, sel[2]);
+    e1.y = __builtin_amdgcn_perm(hi_mm, lo_mm, sel[2]);
+    e1.z = __builtin_amdgcn_perm(hi_met, lo_met, sel[3]);
+    e1.w = __builtin_amdgcn_perm(hi_mm, lo_mm, sel[3]);
+    uint4* dst = reinterpret_cast<uint4*>(tab + lane * 32);
+    dst[0] = e0;
+    dst[1] = e1;
+}
+
+__global__ __launch_bounds__(64) void vit_pk_kernel(const uint8_t* __restrict__ sym, uint8_t* __restrict__ out,
+                                                    const vit_frame_desc* __restrict__ desc,
+                                                    u32 framebits_uniform, long long nframes) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* tab = lds;              // [tau][pair][c] -> (M,MM), later traceback scratch
+    char* dec = lds + TAB_BYTES;  // [block][lane] -> (acc0, acc1), later the output bit image
+    const u32 lane = threadIdx.x;
+    const long long f0 = (long long)blockIdx.x * 4;
+
+    // ---- per-frame parameters (wave-uniform loads) ----
+    u32 fbits[4];
+    size_t soff[4], ooff[4];
+    u32 maxfb = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const long long f = f0 + k;
+        fbits[k] = 0;
+        soff[k] = ooff[k] = 0;
+        if (f < nframes) {
+            if (desc) {
+                fbits[k] = desc[f].framebits;
+                soff[k] = desc[f].sym_offset;
+                ooff[k] = desc[f].out_offset;
+            } else {
+                fbits[k] = framebits_uniform;
+                soff[k] = (size_t)f * 4u * (framebits_uniform + VIT_TAIL);
+                ooff[k] = (size_t)f * (framebits_uniform >> 3);
+            }
+        }
+        maxfb = fbits[k] > maxfb ? fbits[k] : maxfb;
+    }
+    if (maxfb == 0) return;
+    const u32 nblk = (maxfb + VIT_TAIL + 15u) >> 4;
+
+    // ---- ACS-phase lane constants ----
+    const u32 l5 = lane & 31u, pair = lane >> 5;
+    Lanes L;
+#pragma unroll
+    for (int rho = 0; rho < 5; rho++) {
+        const u32 i = ((l5 << rho) | (l5 >> (5 - rho))) & 31u;  // butterfly index rol5(l, rho)
+        const u32 i0 = i & 1u, i1 = (i >> 1) & 1u, i2 = (i >> 2) & 1u, i3 = (i >> 3) & 1u, i4 = (i >> 4) & 1u;
+        const u32 c = (i1 ^ i2 ^ i4) | ((i0 ^ i1 ^ i2) << 1) | ((i0 ^ i3) << 2);  // parity((2i)&poly_j), const.asm:27-63
+        L.toff[rho] = pair * 64u + c * 8u;
+    }
+    // ---- pre-pass lane constants ----
+    const u32 tau = lane >> 2, pk = ((lane >> 1) & 1u) * 2u + (lane & 1u);  // frame index within the group
+    const u32 p_fb = pk == 0 ? fbits[0] : pk == 1 ? fbits[1] : pk == 2 ? fbits[2] : fbits[3];
+    const size_t p_so = pk == 0 ? soff[0] : pk == 1 ? soff[1] : pk == 2 ? soff[2] : soff[3];
+    const u32 p_T = p_fb ? p_fb + VIT_TAIL : 0u;
+    const u32* p_sym = reinterpret_cast<const u32*>(sym + p_so);
+    u32 sel[4];
+    {
+        const u32 hb = (tau & 1u) ? 0x0C000C00u : 0x0D000D00u;  // even step: 0xFF high bytes (= +0xFF00)
+#pragma unroll
+        for (int k = 0; k < 4; k++) sel[k] = hb | (0x00040000u + 0x00010001u * k);  // byte k of lo / hi frame
+    }
+
+    // ---- ACS over all blocks ----
+    u32 A = l5 == 0 ? 0u : 0x003F003Fu, B = 0x003F003Fu;  // const.asm:19-25 (0-based, step 0 is even)
+    u32 acc0 = 0, acc1 = 0;
+    u32 s_cur = tau < p_T ? p_sym[tau] : 0u;
+    u32 v = 0;
+    for (u32 blk = 0; blk < nblk; blk++) {
+        prepass(s_cur, tab, lane, sel);
+        const u32 tn = (blk + 1) * 16u + tau;
+        s_cur = tn < p_T ? p_sym[tn] : 0u;  // prefetch the next block's symbols
+        __syncthreads();
+        switch (v) {
+            case 0: Steps<0, 0>::run(A, B, acc0, acc1, tab, L, lane); break;
+            case 1: Steps<1, 0>::run(A, B, acc0, acc1, tab, L, lane); break;
+            case 2: Steps<2, 0>::run(A, B, acc0, acc1, tab, L, lane); break;
+            case 3: Steps<3, 0>::run(A, B, acc0, acc1, tab, L, lane); break;
+            default: Steps<4, 0>::run(A, B, acc0, acc1, tab, L, lane); break;
+        }
+        v = v == 4 ? 0 : v + 1;
+        *reinterpret_cast<uint2*>(dec + blk * DEC_BLOCK + lane * 8) = make_uint2(acc0, acc1);
+        __syncthreads();
+    }
+
+    // ---- blocked speculative traceback: lane = (frame fi, block q) ----
+    const u32 fi = lane >> 4, q = lane & 15u;
+    const u32 t_fb = fi == 0 ? fbits[0] : fi == 1 ? fbits[1] : fi == 2 ? fbits[2] : fbits[3];
+    const u32 t_T = t_fb + VIT_TAIL;
+    const u32 BL = 5u * ((maxfb + 79u) / 80u);  // 16*BL >= maxfb, multiple of the phase period
+    const u32 tbase = VIT_TAIL + q * BL;
+    const bool has_work = t_fb != 0 && tbase < t_T;
+    const u32 q_top = t_fb ? (t_fb - 1u) / BL : 0u;  // block holding step T-1
+    const u32 pairbase = (fi >> 1) * 256u, halfshift = (fi & 1u) * 16u;
+    u32* scratch = reinterpret_cast<u32*>(tab) + lane * KW;
+    u32 E_in = 0, E_out = 0;
+    bool need = has_work;
+    for (int pass = 0; pass < 17; pass++) {
+        u32 E = E_in, cur = 0;
+        u32 rho = BL % 5u;  // rho of i = BL-1 is (i+1)%5 = BL%5 = 0
+        for (int i = (int)BL - 1; i >= 0; i--) {
+            const u32 t = tbase + (u32)i;
+            const bool act = need && t < t_T;
+            const u32 vv = (E >> 3) & 31u, n = (E >> 2) & 1u;
+            const u32 y = vv | (vv << 5);
+            const u32 l = (y >> rho) & 31u;  // lane that held state E>>2 after step t: ror5(s'>>1, t%5)
+            u32 k = 0;
+            if (act) {
+                const u32 w = *reinterpret_cast<const u32*>(dec + ((t >> 4) << 9) + pairbase + (l << 3) + (n << 2));
+                k = ((w >> ((t & 15u) + halfshift)) & 1u) ^ 1u;  // stored bit = NOT decision
+                E = (E >> 1) | (k << 7);
+            }
+            cur |= k << (i & 31);
+            if ((i & 31) == 0) {
+                if (need) scratch[i >> 5] = cur;
+                cur = 0;
+            }
+            rho = rho == 0 ? 4u : rho - 1u;
+        }
+        if (need) E_out = E;
+        const u32 nxt = __shfl_down(E_out, 1);
+        const u32 new_in = (has_work && q < q_top) ? nxt : 0u;
+        const bool changed = has_work && ((new_in ^ E_in) >> 2) != 0;
+        E_in = new_in;
+        need = changed;
+        if (!__any(changed)) break;
+    }
+    __syncthreads();
+
+    // ---- assemble the output bit image in LDS (decisions are dead now) ----
+    u32* img = reinterpret_cast<u32*>(dec);
+    const u32 fstride = ((maxfb + 31u) >> 5) + 2u;  // dwords per frame, with slack for the shifted spill
+    for (u32 i = lane; i < 4u * fstride; i += 64u) img[i] = 0;
+    __syncthreads();
+    if (has_work) {
+        const u32 nw = (BL + 31u) >> 5;
+        for (u32 w = 0; w < nw; w++) {
+            const u32 val = scratch[w];
+            const u32 b0 = q * BL + 32u * w;  // decoded-bit index of val's bit 0
+            const u32 d = b0 >> 5, sft = b0 & 31u;
+            if (val) {
+                atomicOr(&img[fi * fstride + d], val << sft);
+                if (sft) atomicOr(&img[fi * fstride + d + 1], val >> (32u - sft));
+            }
+        }
+    }
+    __syncthreads();
+    // bit b of the image is decoded bit b; output bytes are MSB-first (deconvolve.cpp:432-433)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u32 nbytes = fbits[k] >> 3;
+        uint8_t* o = out + ooff[k];
+        if (((ooff[k] | nbytes) & 3u) == 0) {
+            for (u32 m = lane; m < (nbytes >> 2); m += 64u)
+                reinterpret_cast<u32*>(o)[m] = __builtin_bswap32(__builtin_bitreverse32(img[k * fstride + m]));
+        } else {
+            for (u32 j = lane; j < nbytes; j += 64u) {
+                const u32 byte = (img[k * fstride + (j >> 2)] >> (8u * (j & 3u))) & 0xFFu;
+                o[j] = (uint8_t)(__builtin_bitreverse32(byte) >> 24);
+            }
+        }
+    }
+}
+
+constexpr u32 PK_MAX_FRAMEBITS = 4096;  // BL <= 256 bits of traceback scratch per lane
+
+size_t pk_lds_bytes(u32 max_framebits) {
+    const u32 nblk = (max_framebits + VIT_TAIL + 15u) >> 4;
+    return (size_t)TAB_BYTES + (size_t)nblk * DEC_BLOCK;
+}
+
+}  // namespace
+
+bool vit_pk_supported(uint32_t max_framebits) {
+    return max_framebits >= 8 && max_framebits <= PK_MAX_FRAMEBITS && (max_framebits % 8u) == 0 &&
+           pk_lds_bytes(max_framebits) <= 160u * 1024u;
+}
+
+hipError_t vit_launch_pk(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_desc* d_desc, uint32_t framebits,
+                         uint32_t max_framebits, int64_t nframes, hipStream_t stream) {
+    if (nframes <= 0) return hipSuccess;
+    if (!vit_pk_supported(max_framebits)) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vit_pk_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const long long groups = (nframes + 3) / 4;
+    if (groups > 0x7FFFFFFFLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(vit_pk_kernel, dim3((unsigned)groups), dim3(64), pk_lds_bytes(max_framebits), stream, d_sym,
+                       d_out, d_desc, framebits, (long long)nframes);
+    return hipGetLastError();
 }

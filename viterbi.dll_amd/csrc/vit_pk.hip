@@ -23,7 +23,12 @@
 // pre-pass (lane = frame x step) computes the 8 pavgb-tree metrics with byte-wide
 // v_lerp_u8 and writes a (M, 63-M) table to LDS; an ACS lane reads its 8 bytes.
 //
-// Traceback.  Blocked and speculative: lane = (frame, block of BL steps); every
+// Decision storage.  LDS (160 KB/CU) is what limits resident waves, so only the
+// SECOND half of a frame's decision history is written to LDS; the first half stays
+// in VGPRs (two 32-dword register arrays indexed with s_set_gpr_idx) and is dumped
+// into the same LDS region after the second half has been traced back.
+//
+// Traceback.  Two parts (second half, then first half), each blocked and speculative: lane = (frame, block of BL steps); every
 // block is traced from state 0, then re-traced from the state its successor block
 // ended in until nothing changes.  The last block really starts in state 0
 // (tail-terminated), so the fixed point is exactly the serial chainback.
@@ -55,38 +60,47 @@ struct Lanes {
 
 // lane-bit <-> register-bit transpose on lane bit J: afterwards A holds the s5=0
 // member and B the s5=1 member of the next butterfly.
+//   A = bit_J(lane) ? N1[lane ^ 2^J] : N0        B = bit_J(lane) ? N1 : N0[lane ^ 2^J]
+// J = 4: v_permlane16_swap.  J < 4: two v_cndmask_b32_dpp (DPP on src0, select by VCC);
+// `s_nop 1` covers the VALU-write -> DPP-read hazard of N0/N1, which hipcc cannot see
+// inside an asm statement.
+struct ExMasks {
+    unsigned long long lo[4], hi[4];  // lanes with bit J clear / set, J = 0..3
+};
+#define VIT_EXCHANGE_ASM(CTRL_A, CTRL_B)                                                                  \
+    asm("s_nop 1\n\t"                                                                                     \
+        "s_mov_b64 vcc, %[mlo]\n\t"                                                                       \
+        "v_cndmask_b32_dpp %[a], %[n1], %[n0], vcc " CTRL_A " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        "s_mov_b64 vcc, %[mhi]\n\t"                                                                       \
+        "v_cndmask_b32_dpp %[b], %[n0], %[n1], vcc " CTRL_B " row_mask:0xf bank_mask:0xf bound_ctrl:1"      \
+        : [a] "=&v"(A), [b] "=&v"(B)                                                                      \
+        : [n0] "v"(N0), [n1] "v"(N1), [mlo] "s"(X.lo[J]), [mhi] "s"(X.hi[J])                              \
+        : "vcc")
 template <int J>
-DEV void exchange(u32& A, u32& B, u32 N0, u32 N1, u32 lane) {
+DEV void exchange(u32& A, u32& B, u32 N0, u32 N1, const ExMasks& X) {
     if constexpr (J == 4) {
         // swap N0's odd rows with N1's even rows (rows = 16 lanes)
         auto r = __builtin_amdgcn_permlane16_swap(N0, N1, false, false);
         A = r[0];
         B = r[1];
     } else if constexpr (J == 3) {
-        A = __builtin_amdgcn_update_dpp(N0, N1, 0x128 /*row_ror:8*/, 0xF, 0xC, false);
-        B = __builtin_amdgcn_update_dpp(N1, N0, 0x128, 0xF, 0x3, false);
+        VIT_EXCHANGE_ASM("row_ror:8", "row_ror:8");
     } else if constexpr (J == 2) {
-        A = __builtin_amdgcn_update_dpp(N0, N1, 0x114 /*row_shr:4*/, 0xF, 0xA, false);
-        B = __builtin_amdgcn_update_dpp(N1, N0, 0x104 /*row_shl:4*/, 0xF, 0x5, false);
+        VIT_EXCHANGE_ASM("row_shr:4", "row_shl:4");
     } else if constexpr (J == 1) {
-        // DPP reads need the SOURCE lane active, so the moves run on all lanes and a select follows
-        const u32 pn1 = __builtin_amdgcn_update_dpp(0u, N1, 0x4E /*quad_perm:[2,3,0,1]*/, 0xF, 0xF, true);
-        const u32 pn0 = __builtin_amdgcn_update_dpp(0u, N0, 0x4E, 0xF, 0xF, true);
-        const bool hi = lane & 2u;
-        A = hi ? pn1 : N0;
-        B = hi ? N1 : pn0;
+        VIT_EXCHANGE_ASM("quad_perm:[2,3,0,1]", "quad_perm:[2,3,0,1]");
     } else {
-        const u32 pn1 = __builtin_amdgcn_update_dpp(0u, N1, 0xB1 /*quad_perm:[1,0,3,2]*/, 0xF, 0xF, true);
-        const u32 pn0 = __builtin_amdgcn_update_dpp(0u, N0, 0xB1, 0xF, 0xF, true);
-        const bool hi = lane & 1u;
-        A = hi ? pn1 : N0;
-        B = hi ? N1 : pn0;
+        VIT_EXCHANGE_ASM("quad_perm:[1,0,3,2]", "quad_perm:[1,0,3,2]");
     }
 }
 
+struct Consts {
+    u32 hi;    // 0xFF00FF00 in a VGPR (second constant of v_and_or_b32)
+};
+
 // One trellis step for 4 frames (deconvolve.cpp:352-374 in packed u16 form).
 template <int RHO, bool ODD>
-DEV void acs_step(u32& A, u32& B, u32& acc0, u32& acc1, uint2 mt, u32 lane) {
+DEV void acs_step(u32& A, u32& B, u32& acc0, u32& acc1, uint2 mt, const ExMasks& X, const Consts& C) {
     const us2 a = U(A), b = U(B), M = U(mt.x), MM = U(mt.y);
     const us2 m0 = __builtin_elementwise_add_sat(a, M), m1 = __builtin_elementwise_add_sat(b, MM);
     const us2 m2 = __builtin_elementwise_add_sat(a, MM), m3 = __builtin_elementwise_add_sat(b, M);
@@ -96,28 +110,34 @@ DEV void acs_step(u32& A, u32& B, u32& acc0, u32& acc1, uint2 mt, u32 lane) {
     acc0 = (W(x01) & 0x80008000u) | W(U(acc0) >> (unsigned short)1);
     acc1 = (W(x23) & 0x80008000u) | W(U(acc1) >> (unsigned short)1);
     if constexpr (ODD) {
-        // Renormalize256: state 0 (lane 0 of the pair, register N0) > 150 -> psubusb 63
+        // Renormalize256: state 0 (lane 0 of the pair, register N0) > 150 -> psubusb 63.
+        // z = m + 0xFF00; z + 0x8069 has bit 15 set iff m >= 151; K = 0xFF00 + (63 if so).
         const u32 z = (u32)__builtin_amdgcn_ds_swizzle((int)W(n0), 0);  // lane 0 of each 32-lane group
-        const us2 over = __builtin_elementwise_sub_sat(U(z), U(0xFF96FF96u));  // > 0 iff metric > 150
-        const us2 K = __builtin_elementwise_min(over, U(0x00010001u)) * U(0x003F003Fu) + U(HI);
-        n0 = __builtin_elementwise_sub_sat(n0, K);  // -> 0-based representation
-        n1 = __builtin_elementwise_sub_sat(n1, K);
+        u32 K;
+        asm("v_pk_add_u16 %0, %1, %2\n\t"
+            "v_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]\n\t"
+            "v_and_or_b32 %0, %0, %3, %4"
+            : "=&v"(K)
+            : "v"(z), "s"(0x80698069u), "s"(0x003F003Fu), "v"(C.hi));
+        n0 = __builtin_elementwise_sub_sat(n0, U(K));  // -> 0-based representation
+        n1 = __builtin_elementwise_sub_sat(n1, U(K));
     }
-    exchange<4 - RHO>(A, B, W(n0), W(n1), lane);
+    exchange<4 - RHO>(A, B, W(n0), W(n1), X);
 }
 
 template <int V, int J>
 struct Steps {
-    static DEV void run(u32& A, u32& B, u32& acc0, u32& acc1, const char* tab, const Lanes& L, u32 lane) {
+    static DEV void run(u32& A, u32& B, u32& acc0, u32& acc1, const char* tab, const Lanes& L, const ExMasks& X,
+                        const Consts& C) {
         constexpr int RHO = (V + J) % 5;
         const uint2 mt = *reinterpret_cast<const uint2*>(tab + L.toff[RHO] + J * 128);
-        acs_step<RHO, (J & 1) != 0>(A, B, acc0, acc1, mt, lane);
-        Steps<V, J + 1>::run(A, B, acc0, acc1, tab, L, lane);
+        acs_step<RHO, (J & 1) != 0>(A, B, acc0, acc1, mt, X, C);
+        Steps<V, J + 1>::run(A, B, acc0, acc1, tab, L, X, C);
     }
 };
 template <int V>
 struct Steps<V, 16> {
-    static DEV void run(u32&, u32&, u32&, u32&, const char*, const Lanes&, u32) {}
+    static DEV void run(u32&, u32&, u32&, u32&, const char*, const Lanes&, const ExMasks&, const Consts&) {}
 };
 
 // Pre-pass for 16 steps: lane = (tau = lane>>2, pair = (lane>>1)&1, half = lane&1).
@@ -157,12 +177,86 @@ DEV void prepass(u32 s, char* tab, u32 lane, const u32 (&sel)[4]) {
     dst[1] = e1;
 }
 
+typedef u32 v32u __attribute__((ext_vector_type(32)));
+constexpr u32 VREG_BLOCKS = 32;  // decision blocks that can stay in VGPRs (2 x 32 dwords)
+
+// Number of leading 16-step blocks whose decisions stay in registers.
+__host__ __device__ inline u32 pk_reg_blocks(u32 nblk) {
+    const u32 h = nblk >> 1;
+    return h < VREG_BLOCKS ? h : VREG_BLOCKS;
+}
+
+// One traceback part over steps [ts, te) of every frame (te per lane's frame, te_max uniform),
+// decisions of block b at dec + (b - slot0)*512.  Lane = (frame fi = lane>>4, block q = lane&15).
+// E_top: the true register value at the frame's last step of this part (per lane's frame).
+// ORs the decoded bits into img and returns E after the part's first step (per lane's frame).
+DEV u32 traceback_part(const char* dec, u32* scratch, u32* img, u32 fstride, u32 lane, u32 ts, u32 te, u32 te_max,
+                       u32 slot0, u32 E_top) {
+    const u32 fi = lane >> 4, q = lane & 15u;
+    const u32 span = te_max > ts ? te_max - ts : 0u;
+    if (span == 0) return E_top;
+    const u32 BL = 5u * ((span + 79u) / 80u);  // 16*BL >= span, multiple of the phase period 5
+    const u32 tbase = ts + q * BL;
+    const bool has_work = tbase < te;
+    const u32 q_top = te > ts ? (te - 1u - ts) / BL : 0u;  // block holding the frame's last step of this part
+    const u32 pairbase = (fi >> 1) * 256u, halfshift = (fi & 1u) * 16u;
+    const u32 rho_last = (ts + BL - 1u) % 5u;  // phase t%5 of i = BL-1
+    u32 E_in = (has_work && q == q_top) ? E_top : 0u, E_out = E_top;
+    bool need = has_work;
+    for (int pass = 0; pass < 17; pass++) {
+        u32 E = E_in, cur = 0;
+        u32 rho = rho_last;
+        for (int i = (int)BL - 1; i >= 0; i--) {
+            const u32 t = tbase + (u32)i;
+            const bool act = need && t < te;
+            const u32 vv = (E >> 3) & 31u, n = (E >> 2) & 1u;
+            const u32 y = vv | (vv << 5);
+            const u32 l = (y >> rho) & 31u;  // lane that held state E>>2 after step t: ror5(s'>>1, t%5)
+            u32 k = 0;
+            if (act) {
+                const u32 w =
+                    *reinterpret_cast<const u32*>(dec + (((t >> 4) - slot0) << 9) + pairbase + (l << 3) + (n << 2));
+                k = ((w >> ((t & 15u) + halfshift)) & 1u) ^ 1u;  // stored bit = NOT decision
+                E = (E >> 1) | (k << 7);
+            }
+            cur |= k << (i & 31);
+            if ((i & 31) == 0) {
+                if (need) scratch[i >> 5] = cur;
+                cur = 0;
+            }
+            rho = rho == 0 ? 4u : rho - 1u;
+        }
+        if (need) E_out = E;
+        const u32 nxt = __shfl_down(E_out, 1);
+        const u32 new_in = !has_work ? 0u : (q < q_top ? nxt : E_top);
+        const bool changed = has_work && ((new_in ^ E_in) >> 2) != 0;
+        E_in = new_in;
+        need = changed;
+        if (!__any(changed)) break;
+    }
+    // decoded bit index of step t is t - 6 (chainback skips the 6 tail decisions)
+    if (has_work) {
+        const u32 nw = (BL + 31u) >> 5;
+        for (u32 w = 0; w < nw; w++) {
+            const u32 val = scratch[w];
+            const u32 b0 = tbase - VIT_TAIL + 32u * w;
+            const u32 d = b0 >> 5, sft = b0 & 31u;
+            if (val) {
+                atomicOr(&img[fi * fstride + d], val << sft);
+                if (sft) atomicOr(&img[fi * fstride + d + 1], val >> (32u - sft));
+            }
+        }
+    }
+    return __shfl(E_out, (int)(fi * 16u));  // block 0 of the frame ends at step ts
+}
+
 __global__ __launch_bounds__(64) void vit_pk_kernel(const uint8_t* __restrict__ sym, uint8_t* __restrict__ out,
                                                     const vit_frame_desc* __restrict__ desc,
-                                                    u32 framebits_uniform, long long nframes) {
+                                                    u32 framebits_uniform, long long nframes, u32 img_bytes) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    char* tab = lds;              // [tau][pair][c] -> (M,MM), later traceback scratch
-    char* dec = lds + TAB_BYTES;  // [block][lane] -> (acc0, acc1), later the output bit image
+    char* tab = lds;                                         // [tau][pair][c] -> (M,MM); later traceback scratch
+    u32* img = reinterpret_cast<u32*>(lds + TAB_BYTES);      // output bit image, 4 frames
+    char* dec = lds + TAB_BYTES + img_bytes;                 // [block - H][lane] -> (acc0, acc1)
     const u32 lane = threadIdx.x;
     const long long f0 = (long long)blockIdx.x * 4;
 
@@ -190,6 +284,9 @@ __global__ __launch_bounds__(64) void vit_pk_kernel(const uint8_t* __restrict__ 
     }
     if (maxfb == 0) return;
     const u32 nblk = (maxfb + VIT_TAIL + 15u) >> 4;
+    const u32 H = pk_reg_blocks(nblk);  // blocks [0,H) in VGPRs, [H,nblk) in LDS
+    const u32 fstride = ((maxfb + 31u) >> 5) + 2u;  // image dwords per frame (+ slack for the shifted spill)
+    for (u32 i = lane; i < 4u * fstride; i += 64u) img[i] = 0;
 
     // ---- ACS-phase lane constants ----
     const u32 l5 = lane & 31u, pair = lane >> 5;
@@ -201,6 +298,14 @@ __global__ __launch_bounds__(64) void vit_pk_kernel(const uint8_t* __restrict__ 
         const u32 c = (i1 ^ i2 ^ i4) | ((i0 ^ i1 ^ i2) << 1) | ((i0 ^ i3) << 2);  // parity((2i)&poly_j), const.asm:27-63
         L.toff[rho] = pair * 64u + c * 8u;
     }
+    ExMasks X;
+    X.lo[0] = 0x5555555555555555ull; X.hi[0] = 0xAAAAAAAAAAAAAAAAull;
+    X.lo[1] = 0x3333333333333333ull; X.hi[1] = 0xCCCCCCCCCCCCCCCCull;
+    X.lo[2] = 0x0F0F0F0F0F0F0F0Full; X.hi[2] = 0xF0F0F0F0F0F0F0F0ull;
+    X.lo[3] = 0x00FF00FF00FF00FFull; X.hi[3] = 0xFF00FF00FF00FF00ull;
+    Consts C;
+    C.hi = HI;
+    asm volatile("" : "+v"(C.hi));  // keep it in a VGPR
     // ---- pre-pass lane constants ----
     const u32 tau = lane >> 2, pk = ((lane >> 1) & 1u) * 2u + (lane & 1u);  // frame index within the group
     const u32 p_fb = pk == 0 ? fbits[0] : pk == 1 ? fbits[1] : pk == 2 ? fbits[2] : fbits[3];
@@ -217,6 +322,7 @@ __global__ __launch_bounds__(64) void vit_pk_kernel(const uint8_t* __restrict__ 
     // ---- ACS over all blocks ----
     u32 A = l5 == 0 ? 0u : 0x003F003Fu, B = 0x003F003Fu;  // const.asm:19-25 (0-based, step 0 is even)
     u32 acc0 = 0, acc1 = 0;
+    v32u r0, r1;  // register-resident decisions of blocks [0,H)
     u32 s_cur = tau < p_T ? p_sym[tau] : 0u;
     u32 v = 0;
     for (u32 blk = 0; blk < nblk; blk++) {
@@ -225,79 +331,46 @@ __global__ __launch_bounds__(64) void vit_pk_kernel(const uint8_t* __restrict__ 
         s_cur = tn < p_T ? p_sym[tn] : 0u;  // prefetch the next block's symbols
         __syncthreads();
         switch (v) {
-            case 0: Steps<0, 0>::run(A, B, acc0, acc1, tab, L, lane); break;
-            case 1: Steps<1, 0>::run(A, B, acc0, acc1, tab, L, lane); break;
-            case 2: Steps<2, 0>::run(A, B, acc0, acc1, tab, L, lane); break;
-            case 3: Steps<3, 0>::run(A, B, acc0, acc1, tab, L, lane); break;
-            default: Steps<4, 0>::run(A, B, acc0, acc1, tab, L, lane); break;
+            case 0: Steps<0, 0>::run(A, B, acc0, acc1, tab, L, X, C); break;
+            case 1: Steps<1, 0>::run(A, B, acc0, acc1, tab, L, X, C); break;
+            case 2: Steps<2, 0>::run(A, B, acc0, acc1, tab, L, X, C); break;
+            case 3: Steps<3, 0>::run(A, B, acc0, acc1, tab, L, X, C); break;
+            default: Steps<4, 0>::run(A, B, acc0, acc1, tab, L, X, C); break;
         }
         v = v == 4 ? 0 : v + 1;
-        *reinterpret_cast<uint2*>(dec + blk * DEC_BLOCK + lane * 8) = make_uint2(acc0, acc1);
+        if (blk < H) {
+            r0[blk] = acc0;  // s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off
+            r1[blk] = acc1;
+        } else {
+            *reinterpret_cast<uint2*>(dec + (blk - H) * DEC_BLOCK + lane * 8) = make_uint2(acc0, acc1);
+        }
         __syncthreads();
     }
 
-    // ---- blocked speculative traceback: lane = (frame fi, block q) ----
-    const u32 fi = lane >> 4, q = lane & 15u;
+    // ---- traceback: lane = (frame fi, block q) ----
+    const u32 fi = lane >> 4;
     const u32 t_fb = fi == 0 ? fbits[0] : fi == 1 ? fbits[1] : fi == 2 ? fbits[2] : fbits[3];
-    const u32 t_T = t_fb + VIT_TAIL;
-    const u32 BL = 5u * ((maxfb + 79u) / 80u);  // 16*BL >= maxfb, multiple of the phase period
-    const u32 tbase = VIT_TAIL + q * BL;
-    const bool has_work = t_fb != 0 && tbase < t_T;
-    const u32 q_top = t_fb ? (t_fb - 1u) / BL : 0u;  // block holding step T-1
-    const u32 pairbase = (fi >> 1) * 256u, halfshift = (fi & 1u) * 16u;
+    const u32 t_T = t_fb ? t_fb + VIT_TAIL : 0u;  // steps of this lane's frame
+    const u32 T_max = maxfb + VIT_TAIL;
     u32* scratch = reinterpret_cast<u32*>(tab) + lane * KW;
-    u32 E_in = 0, E_out = 0;
-    bool need = has_work;
-    for (int pass = 0; pass < 17; pass++) {
-        u32 E = E_in, cur = 0;
-        u32 rho = BL % 5u;  // rho of i = BL-1 is (i+1)%5 = BL%5 = 0
-        for (int i = (int)BL - 1; i >= 0; i--) {
-            const u32 t = tbase + (u32)i;
-            const bool act = need && t < t_T;
-            const u32 vv = (E >> 3) & 31u, n = (E >> 2) & 1u;
-            const u32 y = vv | (vv << 5);
-            const u32 l = (y >> rho) & 31u;  // lane that held state E>>2 after step t: ror5(s'>>1, t%5)
-            u32 k = 0;
-            if (act) {
-                const u32 w = *reinterpret_cast<const u32*>(dec + ((t >> 4) << 9) + pairbase + (l << 3) + (n << 2));
-                k = ((w >> ((t & 15u) + halfshift)) & 1u) ^ 1u;  // stored bit = NOT decision
-                E = (E >> 1) | (k << 7);
-            }
-            cur |= k << (i & 31);
-            if ((i & 31) == 0) {
-                if (need) scratch[i >> 5] = cur;
-                cur = 0;
-            }
-            rho = rho == 0 ? 4u : rho - 1u;
-        }
-        if (need) E_out = E;
-        const u32 nxt = __shfl_down(E_out, 1);
-        const u32 new_in = (has_work && q < q_top) ? nxt : 0u;
-        const bool changed = has_work && ((new_in ^ E_in) >> 2) != 0;
-        E_in = new_in;
-        need = changed;
-        if (!__any(changed)) break;
+    // part 2: steps [max(16H,6), T) from the LDS-resident blocks; the frame ends in state 0
+    const u32 tA = H * 16u;
+    const u32 ts2 = tA > VIT_TAIL ? tA : VIT_TAIL;
+    const u32 E_mid = traceback_part(dec, scratch, img, fstride, lane, ts2, t_T, T_max, H, 0u);
+    __syncthreads();
+    if (H) {
+        // dump the register-resident blocks into the (now dead) LDS decision region
+#pragma unroll
+        for (u32 b = 0; b < VREG_BLOCKS; b++)
+            if (b < H) *reinterpret_cast<uint2*>(dec + b * DEC_BLOCK + lane * 8) = make_uint2(r0[b], r1[b]);
+        __syncthreads();
+        // part 1: steps [6, 16H); a frame that reaches into part 2 continues from E_mid
+        const u32 te1 = t_T < tA ? t_T : tA;
+        const u32 te1_max = T_max < tA ? T_max : tA;
+        traceback_part(dec, scratch, img, fstride, lane, VIT_TAIL, te1, te1_max, 0u, t_T > tA ? E_mid : 0u);
     }
     __syncthreads();
 
-    // ---- assemble the output bit image in LDS (decisions are dead now) ----
-    u32* img = reinterpret_cast<u32*>(dec);
-    const u32 fstride = ((maxfb + 31u) >> 5) + 2u;  // dwords per frame, with slack for the shifted spill
-    for (u32 i = lane; i < 4u * fstride; i += 64u) img[i] = 0;
-    __syncthreads();
-    if (has_work) {
-        const u32 nw = (BL + 31u) >> 5;
-        for (u32 w = 0; w < nw; w++) {
-            const u32 val = scratch[w];
-            const u32 b0 = q * BL + 32u * w;  // decoded-bit index of val's bit 0
-            const u32 d = b0 >> 5, sft = b0 & 31u;
-            if (val) {
-                atomicOr(&img[fi * fstride + d], val << sft);
-                if (sft) atomicOr(&img[fi * fstride + d + 1], val >> (32u - sft));
-            }
-        }
-    }
-    __syncthreads();
     // bit b of the image is decoded bit b; output bytes are MSB-first (deconvolve.cpp:432-433)
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -317,9 +390,10 @@ __global__ __launch_bounds__(64) void vit_pk_kernel(const uint8_t* __restrict__ 
 
 constexpr u32 PK_MAX_FRAMEBITS = 4096;  // BL <= 256 bits of traceback scratch per lane
 
+u32 pk_img_bytes(u32 max_framebits) { return ((4u * (((max_framebits + 31u) >> 5) + 2u) * 4u) + 15u) & ~15u; }
 size_t pk_lds_bytes(u32 max_framebits) {
     const u32 nblk = (max_framebits + VIT_TAIL + 15u) >> 4;
-    return (size_t)TAB_BYTES + (size_t)nblk * DEC_BLOCK;
+    return (size_t)TAB_BYTES + pk_img_bytes(max_framebits) + (size_t)(nblk - pk_reg_blocks(nblk)) * DEC_BLOCK;
 }
 
 }  // namespace
@@ -343,6 +417,6 @@ hipError_t vit_launch_pk(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_d
     const long long groups = (nframes + 3) / 4;
     if (groups > 0x7FFFFFFFLL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(vit_pk_kernel, dim3((unsigned)groups), dim3(64), pk_lds_bytes(max_framebits), stream, d_sym,
-                       d_out, d_desc, framebits, (long long)nframes);
+                       d_out, d_desc, framebits, (long long)nframes, pk_img_bytes(max_framebits));
     return hipGetLastError();
 }

@@ -1,0 +1,197 @@
+"""CPU-only: pins the oracle (test infrastructure) against every known-answer vector that
+exists for this path, and the oracle's two implementations against each other.
+
+What pins it: SURVEY.md section 8c's probe KATs, i.e. outputs of the compiled reference taken
+during the survey (the reference cannot be built under this round's rules: it needs
+stand-ins for <windows.h>/<psapi.h> and MASM constants).  The 16-byte decoder prefix, the
+GF table samples and the two RS behaviours reproduce.  The survey's three FNV-1a-64
+digests do NOT reproduce with any FNV variant tried, so they are recorded as unverified
+(test_survey_fnv_digests_unreproduced) instead of being asserted.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_kat_decoder_prefix(O):
+    # sym[i] = (xorshift64(13,7,17) >> 11) & 255, seed 88172645463325252; the first 16
+    # output bytes are the same for framebits 288 / 768 / 6912
+    want = bytes.fromhex("fa86dfa7873fb335820f0977ead397f7")
+    for fb in (288, 768, 6912):
+        sym = O.uniform_symbols(O.sym_len(fb))
+        out = O.deconvolve_u32(fb, sym.astype(np.uint32))
+        assert out[:16].tobytes() == want
+        assert O.decode_batch(fb, sym)[0][:16].tobytes() == want
+        if O.has_avx2():
+            assert O.decode_batch(fb, sym, avx2=True)[0][:16].tobytes() == want
+
+
+def test_survey_fnv_digests_unreproduced(O):
+    """Documented gap: SURVEY 8c lists FNV-1a-64 digests that this oracle's output does not hash
+    to (nor does any offset/prime/sign/length variant tried in round 1), although the 16-byte
+    prefix from the same run matches.  Kept as a tripwire: if a future change makes them match,
+    promote them to asserted KATs."""
+    survey = {768: 0xCDC63683874489A7, 288: 0xD03B4F5C3A29D635, 6912: 0xCCA725E46A1807EB}
+    hits = 0
+    for fb, dig in survey.items():
+        out = O.deconvolve_u32(fb, O.uniform_symbols(O.sym_len(fb)).astype(np.uint32))
+        hits += O.fnv1a64(out) == dig
+    assert hits in (0, 3)
+    if hits == 3:
+        pytest.fail("survey digests now reproduce: assert them in test_kat_decoder_prefix")
+
+
+def test_kat_gf_tables(O):
+    ato, iof = O.rs_tables()
+    assert ato[:10].tolist() == [1, 2, 4, 8, 16, 32, 64, 128, 29, 58]
+    assert iof[1:6].tolist() == [0, 1, 25, 2, 50]
+    assert iof[0] == 255 and ato.size == 768 and (ato[255:510] == ato[:255]).all()
+    assert (ato[iof[1:].astype(int)] == np.arange(1, 256)).all()
+
+
+def test_kat_rs_behaviour(O):
+    # all-zero 120x12 block with 3 flipped bytes -> 3 and zeros restored
+    p = np.zeros(120 * 12, np.uint8)
+    p[3], p[500], p[1300] = 0x55, 0x01, 0xFF
+    rc, out = O.rs_check_superframe(p, 12)
+    assert rc == 3 and not out.any()
+    # 6 errors in one column -> -1, and nothing at/after that column is written
+    q = np.zeros(120 * 12, np.uint8)
+    q[[5 + 12 * k for k in (1, 9, 20, 33, 47, 90)]] = [7, 99, 3, 200, 5, 66]
+    sentinel = np.full(110 * 12, 0x77, np.uint8)
+    rc, out = O.rs_check_superframe(q, 12, sentinel.copy())
+    assert rc == -1
+    out = out.reshape(110, 12)
+    assert (out[:, 5:] == 0x77).all() and (out[:, :5] == 0).all()
+
+
+def test_rs_corrects_up_to_five(O):
+    rng = np.random.default_rng(0)
+    for ne in range(0, 6):
+        for _ in range(20):
+            msg = rng.integers(0, 256, 110, dtype=np.uint8)
+            cw = O.rs_encode(msg)
+            rc0, _ = O.rs_decode_word(cw)
+            assert rc0 == 0
+            bad = cw.copy()
+            pos = rng.choice(120, ne, replace=False)
+            bad[pos] ^= rng.integers(1, 256, ne, dtype=np.uint8)
+            rc, fixed = O.rs_decode_word(bad)
+            assert rc == ne and np.array_equal(fixed[:110], msg)
+
+
+def test_scalar_equals_avx2_port(O):
+    if not O.has_avx2():
+        pytest.skip("host without AVX2")
+    for fb in (8, 96, 288, 768, 1536, 3072, 6912, 9216):
+        n = 24 if fb <= 3072 else 6
+        sym = np.concatenate([O.noisy_frames(n // 2, fb, seed=fb),
+                              O.uniform_symbols((n // 2) * O.sym_len(fb), seed=fb + 1).reshape(n // 2, -1)])
+        assert np.array_equal(O.decode_batch(fb, sym), O.decode_batch(fb, sym, avx2=True))
+
+
+def test_u32_entry_uses_low_byte_only(O):
+    fb = 768
+    sym = O.uniform_symbols(O.sym_len(fb), seed=2)
+    a = O.deconvolve_u32(fb, sym.astype(np.uint32))
+    b = O.deconvolve_u32(fb, sym.astype(np.uint32) | np.uint32(0xDEAD0000))  # deconvolve.cpp:158-165
+    assert np.array_equal(a, b) and np.array_equal(a, O.decode_batch(fb, sym)[0])
+
+
+def test_renorm_comparator_ge_vs_gt(O):
+    """Appendix A.6: the MASM twins renormalise on >=150, the C path on >150; the survey saw no
+    output difference in 36000 frames.  Same observation here on noisy + adversarial frames."""
+    fb = 768
+    sym = np.concatenate([O.noisy_frames(40, fb, seed=3), O.uniform_symbols(40 * O.sym_len(fb), seed=4).reshape(40, -1)])
+    for s in sym:
+        s32 = s.astype(np.uint32)
+        assert np.array_equal(O.deconvolve_u32(fb, s32), O.deconvolve_u32(fb, s32, ge=True))
+
+
+def test_noise_free_roundtrip_and_ber(O):
+    rng = np.random.default_rng(1)
+    for fb in (8, 768, 3072):
+        bits = rng.integers(0, 2, fb, dtype=np.uint8)
+        sym = (O.encode(bits) * 255).astype(np.uint8)
+        assert np.array_equal(np.unpackbits(O.decode_batch(fb, sym)[0]), bits)
+    # reference-style BER check (viterbi-benchmark.cpp:296-329): Eb/N0 = 3 dB must decode nearly clean
+    sym, bits = O.noisy_frames(50, 3072, seed=9, return_bits=True)
+    out = np.unpackbits(O.decode_batch(3072, sym, nthreads=4), axis=1)
+    ber = (out != bits).mean()
+    assert ber < 2e-3
+
+
+# --- independent cross-check of the natural-order derivation (SURVEY Appendix A.3 from A.4) ---
+# The 96 mask bytes below are DATA: the lane-permuted 256-bit constants exactly as const.asm:27-63
+# lays them out.  The step function works in that permuted order, like the reference's AVX2 path.
+_M256_0347 = bytes.fromhex("0000ffffffff0000ffff00000000ffff" * 2)
+_M256_15 = bytes.fromhex("00ffff00ff0000ff00ffff00ff0000ff" * 2)
+_M256_26 = bytes.fromhex("00ff00ff00ff00ff00ff00ff00ff00ff" + "ff00ff00ff00ff00ff00ff00ff00ff00")
+
+
+def _decode_permuted_order(fb, sym):
+    k0 = np.frombuffer(_M256_0347, np.uint8).astype(np.int32)
+    k1 = np.frombuffer(_M256_15, np.uint8).astype(np.int32)
+    k2 = np.frombuffer(_M256_26, np.uint8).astype(np.int32)
+    avg = lambda a, b: (a + b + 1) >> 1
+    perm = np.r_[0:8, 16:24, 8:16, 24:32]  # qword order [0,2,1,3]: position -> state (vector A)
+    A = np.full(32, 63, np.int32)
+    A[0] = 0
+    B = np.full(32, 63, np.int32)
+    T = ((fb + 6) // 2) * 2
+    dec = np.zeros(T, np.uint64)
+    for t in range(T):
+        s = sym[4 * t:4 * t + 4].astype(np.int32)
+        met = avg(avg(s[0] ^ k0, s[1] ^ k1), avg(s[2] ^ k2, s[3] ^ k0)) >> 2
+        mm = 63 - met
+        m0, m1 = np.minimum(A + met, 255), np.minimum(B + mm, 255)
+        m2, m3 = np.minimum(A + mm, 255), np.minimum(B + met, 255)
+        d0, d1 = m1 <= m0, m3 <= m2
+        sv0, sv1 = np.where(d0, m1, m0), np.where(d1, m3, m2)
+        new = np.zeros(64, np.int32)
+        word = 0
+        for pos in range(32):
+            i = int(perm[pos])  # butterfly held at this position
+            new[2 * i], new[2 * i + 1] = sv0[pos], sv1[pos]
+            word |= (int(d0[pos]) << (2 * i)) | (int(d1[pos]) << (2 * i + 1))
+        dec[t] = word
+        A, B = new[perm], new[perm + 32]
+        if (t & 1) and A[0] > 150:
+            A, B = np.maximum(A - 63, 0), np.maximum(B - 63, 0)
+    out = np.zeros((fb + 7) // 8, np.uint8)
+    E = 0
+    for n in range(fb - 1, -1, -1):
+        k = (int(dec[n + 6]) >> (E >> 2)) & 1
+        E = ((E >> 1) | (k << 7)) & 0xFF
+        out[n >> 3] = E
+    return out
+
+
+def test_permuted_order_restatement_agrees(O):
+    for fb, seed in ((96, 1), (288, 2), (768, 3)):
+        for sym in (O.noisy_frames(1, fb, seed=seed)[0], O.uniform_symbols(O.sym_len(fb), seed=seed)):
+            assert np.array_equal(_decode_permuted_order(fb, sym), O.decode_batch(fb, sym)[0])
+
+
+# --- committed regression fixtures (generated by this oracle, tests/golden/make_golden.py) ---
+
+def test_golden_fixtures(O):
+    with open(os.path.join(GOLD, "golden.json")) as f:
+        g = json.load(f)
+    for case in g["decode"]:
+        fb = case["framebits"]
+        if case["kind"] == "uniform":
+            sym = O.uniform_symbols(O.sym_len(fb), seed=case["seed"])
+        else:
+            sym = O.noisy_frames(1, fb, seed=case["seed"])[0]
+        assert O.fnv1a64(sym) == int(case["sym_fnv1a64"], 16)
+        out = O.decode_batch(fb, sym)[0]
+        assert out.tobytes().hex() == case["out_hex"]
+    for case in g["rs"]:
+        p = np.frombuffer(bytes.fromhex(case["p_hex"]), np.uint8)
+        rc, out = O.rs_check_superframe(p, case["rsdims"], np.full(110 * case["rsdims"], 0xA5, np.uint8))
+        assert rc == case["ret"] and out.tobytes().hex() == case["out_hex"]

@@ -64,126 +64,124 @@ struct Lanes {
 // J = 4: v_permlane16_swap.  J < 4: two v_cndmask_b32_dpp (DPP on src0, select by VCC);
 // `s_nop 1` covers the VALU-write -> DPP-read hazard of N0/N1, which hipcc cannot see
 // inside an asm statement.
-struct ExMasks {
-    unsigned long long lo[4], hi[4];  // lanes with bit J clear / set, J = 0..3
-};
-#define VIT_EXCHANGE_ASM(CTRL_A, CTRL_B)                                                                  \
-    asm("s_nop 1\n\t"                                                                                     \
-        "s_mov_b64 vcc, %[mlo]\n\t"                                                                       \
-        "v_cndmask_b32_dpp %[a], %[n1], %[n0], vcc " CTRL_A " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-        "s_mov_b64 vcc, %[mhi]\n\t"                                                                       \
-        "v_cndmask_b32_dpp %[b], %[n0], %[n1], vcc " CTRL_B " row_mask:0xf bank_mask:0xf bound_ctrl:1"      \
-        : [a] "=&v"(A), [b] "=&v"(B)                                                                      \
-        : [n0] "v"(N0), [n1] "v"(N1), [mlo] "s"(X.lo[J]), [mhi] "s"(X.hi[J])                              \
-        : "vcc")
+// Issue cost on gfx950 (profiles/r01_valu_issue_rates_ubench.txt): every v_pk_*, VOP3 three-operand,
+// DPP and v_cmp instruction holds the SIMD for 4 cycles per wave, v_permlane*_swap for 8, and
+// v_cndmask_b32 through VCC for ~22.  So for J < 4 the partner values travel through the LDS
+// crossbar (ds_swizzle: no VALU slot, no LDS memory) and two v_cndmask_b32_e64 pick them up.
 template <int J>
-DEV void exchange(u32& A, u32& B, u32 N0, u32 N1, const ExMasks& X) {
+DEV void exchange(u32& A, u32& B, u32 N0, u32 N1, u32 lane) {
     if constexpr (J == 4) {
         // swap N0's odd rows with N1's even rows (rows = 16 lanes)
         auto r = __builtin_amdgcn_permlane16_swap(N0, N1, false, false);
         A = r[0];
         B = r[1];
     } else if constexpr (J == 3) {
-        VIT_EXCHANGE_ASM("row_ror:8", "row_ror:8");
+        // masked DPP moves stay in the VALU (10 cycles incl. one copy) and keep LDS latency off this step
+        A = __builtin_amdgcn_update_dpp(N0, N1, 0x128 /*row_ror:8*/, 0xF, 0xC, false);
+        B = __builtin_amdgcn_update_dpp(N1, N0, 0x128, 0xF, 0x3, false);
     } else if constexpr (J == 2) {
-        VIT_EXCHANGE_ASM("row_shr:4", "row_shl:4");
-    } else if constexpr (J == 1) {
-        VIT_EXCHANGE_ASM("quad_perm:[2,3,0,1]", "quad_perm:[2,3,0,1]");
+        A = __builtin_amdgcn_update_dpp(N0, N1, 0x114 /*row_shr:4*/, 0xF, 0xA, false);
+        B = __builtin_amdgcn_update_dpp(N1, N0, 0x104 /*row_shl:4*/, 0xF, 0x5, false);
     } else {
-        VIT_EXCHANGE_ASM("quad_perm:[1,0,3,2]", "quad_perm:[1,0,3,2]");
+        // lane bits 0/1 cannot be masked by DPP bank masks: partner values through ds_swizzle
+        constexpr int pat = 0x1F | ((1 << J) << 10);  // BitMode: src lane = lane ^ 2^J within 32
+        const u32 p1 = (u32)__builtin_amdgcn_ds_swizzle((int)N1, pat);
+        const u32 p0 = (u32)__builtin_amdgcn_ds_swizzle((int)N0, pat);
+        const bool hi = (lane >> J) & 1u;
+        A = hi ? p1 : N0;
+        B = hi ? N1 : p0;
     }
 }
 
 struct Consts {
-    u32 hi;    // 0xFF00FF00 in a VGPR (second constant of v_and_or_b32)
+    u32 hi;  // 0xFF00FF00 in a VGPR
 };
 
 // One trellis step for 4 frames (deconvolve.cpp:352-374 in packed u16 form).
 template <int RHO, bool ODD>
-DEV void acs_step(u32& A, u32& B, u32& acc0, u32& acc1, uint2 mt, const ExMasks& X, const Consts& C) {
+DEV void acs_step(u32& A, u32& B, u32& acc0, u32& acc1, uint2 mt, u32 lane, const Consts& C) {
     const us2 a = U(A), b = U(B), M = U(mt.x), MM = U(mt.y);
     const us2 m0 = __builtin_elementwise_add_sat(a, M), m1 = __builtin_elementwise_add_sat(b, MM);
     const us2 m2 = __builtin_elementwise_add_sat(a, MM), m3 = __builtin_elementwise_add_sat(b, M);
     us2 n0 = __builtin_elementwise_min(m0, m1), n1 = __builtin_elementwise_min(m2, m3);
     // sign(m0-m1) = 1  <=>  m0 < m1  <=>  decision bit 0 (tie -> decision 1)
     const us2 x01 = m0 - m1, x23 = m2 - m3;
-    acc0 = (W(x01) & 0x80008000u) | W(U(acc0) >> (unsigned short)1);
-    acc1 = (W(x23) & 0x80008000u) | W(U(acc1) >> (unsigned short)1);
+    // history: plain 32-bit shift (2 cycles) + v_bfi (4); the bfi also discards the bit that the
+    // 32-bit shift carries from the upper half into bit 15
+    acc0 = (W(x01) & 0x80008000u) | ((acc0 >> 1) & 0x7FFF7FFFu);
+    acc1 = (W(x23) & 0x80008000u) | ((acc1 >> 1) & 0x7FFF7FFFu);
     if constexpr (ODD) {
         // Renormalize256: state 0 (lane 0 of the pair, register N0) > 150 -> psubusb 63.
-        // z = m + 0xFF00; z + 0x8069 has bit 15 set iff m >= 151; K = 0xFF00 + (63 if so).
+        // z = m + 0xFF00 per half.  z + 0x8069 has bit 15 set iff m >= 151; done as ONE 32-bit add:
+        // the low half always carries out (0xFF00 + 0x8069 >= 2^16), so the high constant is 0x8068.
         const u32 z = (u32)__builtin_amdgcn_ds_swizzle((int)W(n0), 0);  // lane 0 of each 32-lane group
-        u32 K;
-        asm("v_pk_add_u16 %0, %1, %2\n\t"
-            "v_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]\n\t"
-            "v_and_or_b32 %0, %0, %3, %4"
-            : "=&v"(K)
-            : "v"(z), "s"(0x80698069u), "s"(0x003F003Fu), "v"(C.hi));
-        n0 = __builtin_elementwise_sub_sat(n0, U(K));  // -> 0-based representation
+        const u32 w = z + 0x80688069u;
+        const u32 t = (w >> 15) & 0x00010001u;
+        const u32 K = t * 63u + C.hi;  // v_mad_u32_u24: 0xFF00 + {0,63} per half
+        n0 = __builtin_elementwise_sub_sat(n0, U(K));           // -> 0-based representation
         n1 = __builtin_elementwise_sub_sat(n1, U(K));
     }
-    exchange<4 - RHO>(A, B, W(n0), W(n1), X);
+    exchange<4 - RHO>(A, B, W(n0), W(n1), lane);
 }
 
 template <int V, int J>
 struct Steps {
-    static DEV void run(u32& A, u32& B, u32& acc0, u32& acc1, const char* tab, const Lanes& L, const ExMasks& X,
+    static DEV void run(u32& A, u32& B, u32& acc0, u32& acc1, const char* tab, const Lanes& L, u32 lane,
                         const Consts& C) {
         constexpr int RHO = (V + J) % 5;
         const uint2 mt = *reinterpret_cast<const uint2*>(tab + L.toff[RHO] + J * 128);
-        acs_step<RHO, (J & 1) != 0>(A, B, acc0, acc1, mt, X, C);
-        Steps<V, J + 1>::run(A, B, acc0, acc1, tab, L, X, C);
+        acs_step<RHO, (J & 1) != 0>(A, B, acc0, acc1, mt, lane, C);
+        Steps<V, J + 1>::run(A, B, acc0, acc1, tab, L, lane, C);
     }
 };
 template <int V>
 struct Steps<V, 16> {
-    static DEV void run(u32&, u32&, u32&, u32&, const char*, const Lanes&, const ExMasks&, const Consts&) {}
+    static DEV void run(u32&, u32&, u32&, u32&, const char*, const Lanes&, u32, const Consts&) {}
 };
 
-// Pre-pass for 16 steps: lane = (tau = lane>>2, pair = (lane>>1)&1, half = lane&1).
-// s = the 4 soft symbols (bytes) of this lane's frame at step t0+tau.
-DEV void prepass(u32 s, char* tab, u32 lane, const u32 (&sel)[4]) {
-    // pavgb tree shared between the 8 mask triples c = b0 | b1<<1 | b2<<2:
-    // metric(c) = avg(avg(s0^B0, s1^B1), avg(s2^B2, s3^B0)) >> 2   (b3 = b0)
+// Four of the 8 pavgb-tree metrics of one frame-step: s = its 4 soft symbols (bytes).
+// metric(c) = avg(avg(s0^B0, s1^B1), avg(s2^B2, s3^B0)) >> 2 for the mask triple
+// c = b0 | b1<<1 | b2<<2 (b3 = b0); returns the 4 metrics with b2 = qsel's half as bytes b0 + 2*b1.
+DEV u32 met4(u32 s, u32 qsel) {
     const u32 r0 = __builtin_amdgcn_perm(s, s, 0x00000000u) ^ 0xFF00FF00u;  // s0 ^ B0, byte pos = b0 + 2*b1
     const u32 r1 = __builtin_amdgcn_perm(s, s, 0x01010101u) ^ 0xFFFF0000u;  // s1 ^ B1
     const u32 r2 = __builtin_amdgcn_perm(s, s, 0x02020202u) ^ 0xFFFF0000u;  // s2 ^ B2, byte pos = b0 + 2*b2
     const u32 r3 = __builtin_amdgcn_perm(s, s, 0x03030303u) ^ 0xFF00FF00u;  // s3 ^ B0
     const u32 P = avg4(r0, r1), Q = avg4(r2, r3);
-    const u32 qlo = __builtin_amdgcn_perm(Q, Q, 0x01000100u);  // [Q(b0,b2=0)] aligned to P's (b0,b1)
-    const u32 qhi = __builtin_amdgcn_perm(Q, Q, 0x03020302u);  // b2 = 1
-    const u32 metlo = (avg4(P, qlo) >> 2) & 0x3F3F3F3Fu;  // c = 0..3
-    const u32 methi = (avg4(P, qhi) >> 2) & 0x3F3F3F3Fu;  // c = 4..7
-    const u32 mmlo = 0x3F3F3F3Fu - metlo, mmhi = 0x3F3F3F3Fu - methi;
-    // combine the two frames of the pair (partner = lane^1): half 0 builds c=0..3, half 1 c=4..7
-    const bool h = lane & 1u;
-    const u32 mine_met = h ? methi : metlo, mine_mm = h ? mmhi : mmlo;
-    const u32 send_met = h ? metlo : methi, send_mm = h ? mmlo : mmhi;
-    const u32 part_met = __builtin_amdgcn_update_dpp(0u, send_met, 0xB1, 0xF, 0xF, true);
-    const u32 part_mm = __builtin_amdgcn_update_dpp(0u, send_mm, 0xB1, 0xF, 0xF, true);
-    const u32 lo_met = h ? part_met : mine_met, hi_met = h ? mine_met : part_met;  // frame half 0 / half 1
-    const u32 lo_mm = h ? part_mm : mine_mm, hi_mm = h ? mine_mm : part_mm;
-    uint4 e0, e1;  // (M,MM) x 4 triples; sel[] also injects +0xFF00 on even steps
-    e0.x = __builtin_amdgcn_perm(hi_met, lo_met, sel[0]);
-    e0.y = __builtin_amdgcn_perm(hi_mm, lo_mm, sel[0]);
-    e0.z = __builtin_amdgcn_perm(hi_met, lo_met, sel[1]);
-    e0.w = __builtin_amdgcn_perm(hi_mm, lo_mm, sel[1]);
-    e1.x = __builtin_amdgcn_perm(hi_met, lo_met, sel[2]);
-    e1.y = __builtin_amdgcn_perm(hi_mm, lo_mm, sel[2]);
-    e1.z = __builtin_amdgcn_perm(hi_met, lo_met, sel[3]);
-    e1.w = __builtin_amdgcn_perm(hi_mm, lo_mm, sel[3]);
+    const u32 q = __builtin_amdgcn_perm(Q, Q, qsel);  // Q(b0, b2) aligned to P's (b0,b1)
+    return (avg4(P, q) >> 2) & 0x3F3F3F3Fu;
+}
+
+// Pre-pass for 16 steps: lane = (tau = lane>>2, pair = (lane>>1)&1, b2 = lane&1) computes, for
+// step t0+tau, the (M, 63-M) entries of the four triples with its b2 for BOTH frames of its pair
+// and writes its 32 table bytes; no cross-lane traffic.
+DEV void prepass(u32 sa, u32 sb, char* tab, u32 lane, u32 qsel, const u32 (&sel)[4]) {
+    const u32 a = met4(sa, qsel), b = met4(sb, qsel);  // frame half 0 / half 1 of the ACS registers
+    const u32 am = 0x3F3F3F3Fu - a, bm = 0x3F3F3F3Fu - b;
     uint4* dst = reinterpret_cast<uint4*>(tab + lane * 32);
-    dst[0] = e0;
-    dst[1] = e1;
+    // sel[k]: byte k of the half-0 word, byte k of the half-1 word, and 0xFF high bytes (+0xFF00) on even steps
+    dst[0] = make_uint4(__builtin_amdgcn_perm(b, a, sel[0]), __builtin_amdgcn_perm(bm, am, sel[0]),
+                        __builtin_amdgcn_perm(b, a, sel[1]), __builtin_amdgcn_perm(bm, am, sel[1]));
+    dst[1] = make_uint4(__builtin_amdgcn_perm(b, a, sel[2]), __builtin_amdgcn_perm(bm, am, sel[2]),
+                        __builtin_amdgcn_perm(b, a, sel[3]), __builtin_amdgcn_perm(bm, am, sel[3]));
 }
 
 typedef u32 v32u __attribute__((ext_vector_type(32)));
 constexpr u32 VREG_BLOCKS = 32;  // decision blocks that can stay in VGPRs (2 x 32 dwords)
 
-// Number of leading 16-step blocks whose decisions stay in registers.
+constexpr u32 DUMP_GROUP = 16;   // register blocks are dumped to LDS 16 at a time
+
+// Number of leading 16-step blocks whose decisions stay in registers; the remaining
+// nblk - R (>= 16 when R > 0) live in LDS, whose region is then reused for the dumps.
 __host__ __device__ inline u32 pk_reg_blocks(u32 nblk) {
-    const u32 h = nblk >> 1;
-    return h < VREG_BLOCKS ? h : VREG_BLOCKS;
+    if (nblk <= DUMP_GROUP) return 0;
+    const u32 r = nblk - DUMP_GROUP;
+    return r < VREG_BLOCKS ? r : VREG_BLOCKS;
+}
+__host__ __device__ inline u32 pk_lds_blocks(u32 nblk) {
+    const u32 r = pk_reg_blocks(nblk);
+    const u32 l = nblk - r;
+    return (r && l < DUMP_GROUP) ? DUMP_GROUP : l;
 }
 
 // One traceback part over steps [ts, te) of every frame (te per lane's frame, te_max uniform),
@@ -256,7 +254,7 @@ __global__ __launch_bounds__(64) void vit_pk_kernel(const uint8_t* __restrict__ 
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* tab = lds;                                         // [tau][pair][c] -> (M,MM); later traceback scratch
     u32* img = reinterpret_cast<u32*>(lds + TAB_BYTES);      // output bit image, 4 frames
-    char* dec = lds + TAB_BYTES + img_bytes;                 // [block - H][lane] -> (acc0, acc1)
+    char* dec = lds + TAB_BYTES + img_bytes;                 // [block - R][lane] -> (acc0, acc1)
     const u32 lane = threadIdx.x;
     const long long f0 = (long long)blockIdx.x * 4;
 
@@ -284,7 +282,7 @@ __global__ __launch_bounds__(64) void vit_pk_kernel(const uint8_t* __restrict__ 
     }
     if (maxfb == 0) return;
     const u32 nblk = (maxfb + VIT_TAIL + 15u) >> 4;
-    const u32 H = pk_reg_blocks(nblk);  // blocks [0,H) in VGPRs, [H,nblk) in LDS
+    const u32 R = pk_reg_blocks(nblk);  // blocks [0,R) in VGPRs, [R,nblk) in LDS
     const u32 fstride = ((maxfb + 31u) >> 5) + 2u;  // image dwords per frame (+ slack for the shifted spill)
     for (u32 i = lane; i < 4u * fstride; i += 64u) img[i] = 0;
 
@@ -298,76 +296,74 @@ __global__ __launch_bounds__(64) void vit_pk_kernel(const uint8_t* __restrict__ 
         const u32 c = (i1 ^ i2 ^ i4) | ((i0 ^ i1 ^ i2) << 1) | ((i0 ^ i3) << 2);  // parity((2i)&poly_j), const.asm:27-63
         L.toff[rho] = pair * 64u + c * 8u;
     }
-    ExMasks X;
-    X.lo[0] = 0x5555555555555555ull; X.hi[0] = 0xAAAAAAAAAAAAAAAAull;
-    X.lo[1] = 0x3333333333333333ull; X.hi[1] = 0xCCCCCCCCCCCCCCCCull;
-    X.lo[2] = 0x0F0F0F0F0F0F0F0Full; X.hi[2] = 0xF0F0F0F0F0F0F0F0ull;
-    X.lo[3] = 0x00FF00FF00FF00FFull; X.hi[3] = 0xFF00FF00FF00FF00ull;
     Consts C;
     C.hi = HI;
     asm volatile("" : "+v"(C.hi));  // keep it in a VGPR
-    // ---- pre-pass lane constants ----
-    const u32 tau = lane >> 2, pk = ((lane >> 1) & 1u) * 2u + (lane & 1u);  // frame index within the group
-    const u32 p_fb = pk == 0 ? fbits[0] : pk == 1 ? fbits[1] : pk == 2 ? fbits[2] : fbits[3];
-    const size_t p_so = pk == 0 ? soff[0] : pk == 1 ? soff[1] : pk == 2 ? soff[2] : soff[3];
-    const u32 p_T = p_fb ? p_fb + VIT_TAIL : 0u;
-    const u32* p_sym = reinterpret_cast<const u32*>(sym + p_so);
+    // ---- pre-pass lane constants: lane = (tau = lane>>2, pair pp = (lane>>1)&1, b2 = lane&1) ----
+    const u32 tau = lane >> 2, pp = (lane >> 1) & 1u;
+    const u32 a_fb = pp ? fbits[2] : fbits[0], b_fb = pp ? fbits[3] : fbits[1];
+    const u32 a_T = a_fb ? a_fb + VIT_TAIL : 0u, b_T = b_fb ? b_fb + VIT_TAIL : 0u;
+    const u32* a_sym = reinterpret_cast<const u32*>(sym + (pp ? soff[2] : soff[0]));
+    const u32* b_sym = reinterpret_cast<const u32*>(sym + (pp ? soff[3] : soff[1]));
+    const u32 qsel = (lane & 1u) ? 0x03020302u : 0x01000100u;
     u32 sel[4];
     {
         const u32 hb = (tau & 1u) ? 0x0C000C00u : 0x0D000D00u;  // even step: 0xFF high bytes (= +0xFF00)
 #pragma unroll
-        for (int k = 0; k < 4; k++) sel[k] = hb | (0x00040000u + 0x00010001u * k);  // byte k of lo / hi frame
+        for (int k = 0; k < 4; k++) sel[k] = hb | (0x00040000u + 0x00010001u * k);  // byte k of half 0 / half 1
     }
 
     // ---- ACS over all blocks ----
     u32 A = l5 == 0 ? 0u : 0x003F003Fu, B = 0x003F003Fu;  // const.asm:19-25 (0-based, step 0 is even)
     u32 acc0 = 0, acc1 = 0;
-    v32u r0, r1;  // register-resident decisions of blocks [0,H)
-    u32 s_cur = tau < p_T ? p_sym[tau] : 0u;
+    v32u r0, r1;  // register-resident decisions of blocks [0,R)
+    u32 sa = tau < a_T ? a_sym[tau] : 0u, sb = tau < b_T ? b_sym[tau] : 0u;
     u32 v = 0;
     for (u32 blk = 0; blk < nblk; blk++) {
-        prepass(s_cur, tab, lane, sel);
+        prepass(sa, sb, tab, lane, qsel, sel);
         const u32 tn = (blk + 1) * 16u + tau;
-        s_cur = tn < p_T ? p_sym[tn] : 0u;  // prefetch the next block's symbols
+        sa = tn < a_T ? a_sym[tn] : 0u;  // prefetch the next block's symbols
+        sb = tn < b_T ? b_sym[tn] : 0u;
         __syncthreads();
         switch (v) {
-            case 0: Steps<0, 0>::run(A, B, acc0, acc1, tab, L, X, C); break;
-            case 1: Steps<1, 0>::run(A, B, acc0, acc1, tab, L, X, C); break;
-            case 2: Steps<2, 0>::run(A, B, acc0, acc1, tab, L, X, C); break;
-            case 3: Steps<3, 0>::run(A, B, acc0, acc1, tab, L, X, C); break;
-            default: Steps<4, 0>::run(A, B, acc0, acc1, tab, L, X, C); break;
+            case 0: Steps<0, 0>::run(A, B, acc0, acc1, tab, L, lane, C); break;
+            case 1: Steps<1, 0>::run(A, B, acc0, acc1, tab, L, lane, C); break;
+            case 2: Steps<2, 0>::run(A, B, acc0, acc1, tab, L, lane, C); break;
+            case 3: Steps<3, 0>::run(A, B, acc0, acc1, tab, L, lane, C); break;
+            default: Steps<4, 0>::run(A, B, acc0, acc1, tab, L, lane, C); break;
         }
         v = v == 4 ? 0 : v + 1;
-        if (blk < H) {
+        if (blk < R) {
             r0[blk] = acc0;  // s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off
             r1[blk] = acc1;
         } else {
-            *reinterpret_cast<uint2*>(dec + (blk - H) * DEC_BLOCK + lane * 8) = make_uint2(acc0, acc1);
+            *reinterpret_cast<uint2*>(dec + (blk - R) * DEC_BLOCK + lane * 8) = make_uint2(acc0, acc1);
         }
-        __syncthreads();
+        __syncthreads();  // table is rewritten by the next pre-pass
     }
 
-    // ---- traceback: lane = (frame fi, block q) ----
+    // ---- traceback, last part first: lane = (frame fi, block q) ----
     const u32 fi = lane >> 4;
     const u32 t_fb = fi == 0 ? fbits[0] : fi == 1 ? fbits[1] : fi == 2 ? fbits[2] : fbits[3];
     const u32 t_T = t_fb ? t_fb + VIT_TAIL : 0u;  // steps of this lane's frame
     const u32 T_max = maxfb + VIT_TAIL;
     u32* scratch = reinterpret_cast<u32*>(tab) + lane * KW;
-    // part 2: steps [max(16H,6), T) from the LDS-resident blocks; the frame ends in state 0
-    const u32 tA = H * 16u;
-    const u32 ts2 = tA > VIT_TAIL ? tA : VIT_TAIL;
-    const u32 E_mid = traceback_part(dec, scratch, img, fstride, lane, ts2, t_T, T_max, H, 0u);
-    __syncthreads();
-    if (H) {
-        // dump the register-resident blocks into the (now dead) LDS decision region
+    // LDS-resident blocks [R, nblk): steps [max(16R,6), T); every frame ends in state 0
+    u32 t_hi = R * 16u;  // steps >= t_hi are done
+    u32 E_next = traceback_part(dec, scratch, img, fstride, lane, t_hi > VIT_TAIL ? t_hi : VIT_TAIL, t_T, T_max, R, 0u);
+    // register-resident blocks, 16 at a time from the top
+    for (u32 g1 = R; g1 > 0;) {
+        const u32 g0 = g1 > DUMP_GROUP ? g1 - DUMP_GROUP : 0u;  // group = blocks [g0, g1)
+        __syncthreads();
 #pragma unroll
         for (u32 b = 0; b < VREG_BLOCKS; b++)
-            if (b < H) *reinterpret_cast<uint2*>(dec + b * DEC_BLOCK + lane * 8) = make_uint2(r0[b], r1[b]);
+            if (b >= g0 && b < g1) *reinterpret_cast<uint2*>(dec + (b - g0) * DEC_BLOCK + lane * 8) = make_uint2(r0[b], r1[b]);
         __syncthreads();
-        // part 1: steps [6, 16H); a frame that reaches into part 2 continues from E_mid
-        const u32 te1 = t_T < tA ? t_T : tA;
-        const u32 te1_max = T_max < tA ? T_max : tA;
-        traceback_part(dec, scratch, img, fstride, lane, VIT_TAIL, te1, te1_max, 0u, t_T > tA ? E_mid : 0u);
+        const u32 ts = g0 ? g0 * 16u : VIT_TAIL, tend = g1 * 16u;
+        const u32 te = t_T < tend ? t_T : tend, te_max = T_max < tend ? T_max : tend;
+        // a frame that reaches beyond this group continues from the state the later part ended in
+        E_next = traceback_part(dec, scratch, img, fstride, lane, ts, te, te_max, g0, t_T > tend ? E_next : 0u);
+        g1 = g0;
     }
     __syncthreads();
 
@@ -393,7 +389,7 @@ constexpr u32 PK_MAX_FRAMEBITS = 4096;  // BL <= 256 bits of traceback scratch p
 u32 pk_img_bytes(u32 max_framebits) { return ((4u * (((max_framebits + 31u) >> 5) + 2u) * 4u) + 15u) & ~15u; }
 size_t pk_lds_bytes(u32 max_framebits) {
     const u32 nblk = (max_framebits + VIT_TAIL + 15u) >> 4;
-    return (size_t)TAB_BYTES + pk_img_bytes(max_framebits) + (size_t)(nblk - pk_reg_blocks(nblk)) * DEC_BLOCK;
+    return (size_t)TAB_BYTES + pk_img_bytes(max_framebits) + (size_t)pk_lds_blocks(nblk) * DEC_BLOCK;
 }
 
 }  // namespace

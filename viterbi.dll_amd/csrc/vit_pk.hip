@@ -47,6 +47,12 @@ typedef uint32_t u32;
 
 DEV us2 U(u32 x) { return __builtin_bit_cast(us2, x); }
 DEV u32 W(us2 x) { return __builtin_bit_cast(u32, x); }
+// v_bfi_b32: (mask & a) | (~mask & b); asm so that hipcc does not split it into and/or chains
+DEV u32 bfi(u32 mask, u32 a, u32 b) {
+    u32 d;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(mask), "v"(a), "v"(b));
+    return d;
+}
 DEV u32 avg4(u32 a, u32 b) { return __builtin_amdgcn_lerp(a, b, 0x01010101u); }  // pavgb x4
 
 constexpr int TAB_BYTES = 2048;  // 16 steps x 2 pairs x 8 triples x (M,MM) 8 B
@@ -108,8 +114,8 @@ DEV void acs_step(u32& A, u32& B, u32& acc0, u32& acc1, uint2 mt, u32 lane, cons
     const us2 x01 = m0 - m1, x23 = m2 - m3;
     // history: plain 32-bit shift (2 cycles) + v_bfi (4); the bfi also discards the bit that the
     // 32-bit shift carries from the upper half into bit 15
-    acc0 = (W(x01) & 0x80008000u) | ((acc0 >> 1) & 0x7FFF7FFFu);
-    acc1 = (W(x23) & 0x80008000u) | ((acc1 >> 1) & 0x7FFF7FFFu);
+    acc0 = bfi(0x80008000u, W(x01), acc0 >> 1);
+    acc1 = bfi(0x80008000u, W(x23), acc1 >> 1);
     if constexpr (ODD) {
         // Renormalize256: state 0 (lane 0 of the pair, register N0) > 150 -> psubusb 63.
         // z = m + 0xFF00 per half.  z + 0x8069 has bit 15 set iff m >= 151; done as ONE 32-bit add:
@@ -184,60 +190,87 @@ __host__ __device__ inline u32 pk_lds_blocks(u32 nblk) {
     return (r && l < DUMP_GROUP) ? DUMP_GROUP : l;
 }
 
+// ---- traceback -------------------------------------------------------------------------------
+// The path is followed in PHYSICAL coordinates: (l, n) = lane (within the pair) and register
+// (N0/N1) that held the survivor decision of the state on the path after step t.  With
+// j = 4 - ((t-1) mod 5), the lane bit exchanged before step t, one step back is
+//     n' = bit j of l,   l' = l with bit j replaced by the decision k read at step t
+// (this is ChainBack's E = (E>>1)|(k<<7), deconvolve.cpp:424-433, seen through the rotating
+// lane<->state map).  The history words hold NOT k, so the code tracks the complement
+// P = (31-l)<<3 | (1-n)<<2: inserting the stored bit unchanged, and 252 - P is the byte
+// offset of the word to read.  State 0 is P = 252.
+constexpr u32 P_ZERO = 252u;
+constexpr u32 TB_WARM = 30u;  // warm-up steps a speculative block starts above its own range
+
 // One traceback part over steps [ts, te) of every frame (te per lane's frame, te_max uniform),
-// decisions of block b at dec + (b - slot0)*512.  Lane = (frame fi = lane>>4, block q = lane&15).
-// E_top: the true register value at the frame's last step of this part (per lane's frame).
-// ORs the decoded bits into img and returns E after the part's first step (per lane's frame).
+// decisions of block b at dec + (b - slot0)*512.  Lane = (frame fi = lane>>4, block q = lane&15)
+// takes the BL steps from ts + q*BL.  A block whose warm-up reaches the frame's last step of the
+// part starts from the true position P_top; the others start TB_WARM steps early from state 0,
+// which merges with the true path with high probability.  Afterwards every speculative block is
+// checked against the block above it and re-traced until nothing changes, so the result is
+// exactly the serial chainback.  ORs the decoded bits into img; returns P after step ts.
 DEV u32 traceback_part(const char* dec, u32* scratch, u32* img, u32 fstride, u32 lane, u32 ts, u32 te, u32 te_max,
-                       u32 slot0, u32 E_top) {
+                       u32 slot0, u32 P_top) {
     const u32 fi = lane >> 4, q = lane & 15u;
     const u32 span = te_max > ts ? te_max - ts : 0u;
-    if (span == 0) return E_top;
+    if (span == 0) return P_top;
     const u32 BL = 5u * ((span + 79u) / 80u);  // 16*BL >= span, multiple of the phase period 5
     const u32 tbase = ts + q * BL;
     const bool has_work = tbase < te;
-    const u32 q_top = te > ts ? (te - 1u - ts) / BL : 0u;  // block holding the frame's last step of this part
-    const u32 pairbase = (fi >> 1) * 256u, halfshift = (fi & 1u) * 16u;
-    const u32 rho_last = (ts + BL - 1u) % 5u;  // phase t%5 of i = BL-1
-    u32 E_in = (has_work && q == q_top) ? E_top : 0u, E_out = E_top;
+    const u32 i_last = has_work ? te - 1u - tbase : 0u;  // block-relative index of the frame's last step here
+    const u32 q_top = te > ts ? (te - 1u - ts) / BL : 0u;
+    const u32 i_warm = BL - 1u + TB_WARM;
+    const u32 i_start = i_last < i_warm ? i_last : i_warm;
+    const bool fixed = has_work && i_last <= i_warm;  // starts from the true position: never re-traced
+    // LDS byte address of the word for (t, P): base + ((t>>4)<<9) - P ; base folds pair, slot0 and the 252
+    const char* base = dec + (fi >> 1) * 256u + P_ZERO - (slot0 << 9);
+    const u32 halfshift = (fi & 1u) * 16u;
+    const u32 j0 = (4u + 5u - ((ts + 5u - 1u) % 5u)) % 5u;  // j of block-relative index 0: 4 - ((ts-1) mod 5)
+
+    u32 P = fixed ? P_top : P_ZERO, P_in = P, P_end = P, P_out = P_top;
     bool need = has_work;
-    for (int pass = 0; pass < 17; pass++) {
-        u32 E = E_in, cur = 0;
-        u32 rho = rho_last;
-        for (int i = (int)BL - 1; i >= 0; i--) {
-            const u32 t = tbase + (u32)i;
-            const bool act = need && t < te;
-            const u32 vv = (E >> 3) & 31u, n = (E >> 2) & 1u;
-            const u32 y = vv | (vv << 5);
-            const u32 l = (y >> rho) & 31u;  // lane that held state E>>2 after step t: ror5(s'>>1, t%5)
-            u32 k = 0;
-            if (act) {
-                const u32 w =
-                    *reinterpret_cast<const u32*>(dec + (((t >> 4) - slot0) << 9) + pairbase + (l << 3) + (n << 2));
-                k = ((w >> ((t & 15u) + halfshift)) & 1u) ^ 1u;  // stored bit = NOT decision
-                E = (E >> 1) | (k << 7);
+    int i_from = (int)i_warm;
+    for (int pass = 0; pass < 18; pass++) {
+        u32 cur = 0;
+        // j(i) = (j0 - i) mod 5
+        u32 jj = 3u + (j0 + 5u - ((u32)i_from % 5u)) % 5u;  // bit position of lane bit j inside P
+        for (int i = i_from; i >= 0; i--) {
+            if (i == (int)BL - 1) P_end = (need && i_start >= BL - 1u) ? P : P_end;
+            if (need && (u32)i <= i_start) {
+                const u32 t = tbase + (u32)i;
+                const u32 w = *reinterpret_cast<const u32*>(base + ((t << 5) & ~511u) - P);
+                const u32 kb = (w >> ((t & 15u) | halfshift)) & 1u;  // stored bit = NOT decision
+                const u32 b = (P >> jj) & 1u;
+                P = (P & ~((1u << jj) | 4u)) | (kb << jj) | (b << 2);
+                if (i < (int)BL) cur |= kb << (i & 31);  // warm-up steps leave no bits
             }
-            cur |= k << (i & 31);
-            if ((i & 31) == 0) {
+            if (i < (int)BL && (i & 31) == 0) {
                 if (need) scratch[i >> 5] = cur;
                 cur = 0;
             }
-            rho = rho == 0 ? 4u : rho - 1u;
+            jj = jj == 7u ? 3u : jj + 1u;
         }
-        if (need) E_out = E;
-        const u32 nxt = __shfl_down(E_out, 1);
-        const u32 new_in = !has_work ? 0u : (q < q_top ? nxt : E_top);
-        const bool changed = has_work && ((new_in ^ E_in) >> 2) != 0;
-        E_in = new_in;
+        if (need) P_out = P;
+        if (pass == 0) P_in = P_end;  // what the warm-up trace passed through at the block's top
+        const u32 nxt = __shfl_down(P_out, 1);
+        const u32 new_in = (q < q_top) ? nxt : P_top;
+        const bool changed = has_work && !fixed && new_in != P_in;
         need = changed;
         if (!__any(changed)) break;
+        P_in = changed ? new_in : P_in;
+        P = new_in;
+        i_from = (int)BL - 1;
     }
-    // decoded bit index of step t is t - 6 (chainback skips the 6 tail decisions)
+    // decoded bit index of step t is t - 6 (chainback skips the 6 tail decisions); decoded bit = NOT stored bit
     if (has_work) {
+        const u32 nvalid = i_last + 1u < BL ? i_last + 1u : BL;
         const u32 nw = (BL + 31u) >> 5;
         for (u32 w = 0; w < nw; w++) {
-            const u32 val = scratch[w];
-            const u32 b0 = tbase - VIT_TAIL + 32u * w;
+            const u32 lo = 32u * w;
+            const u32 cnt = nvalid > lo ? nvalid - lo : 0u;
+            const u32 mask = cnt >= 32u ? 0xFFFFFFFFu : ((1u << cnt) - 1u);
+            const u32 val = ~scratch[w] & mask;
+            const u32 b0 = tbase - VIT_TAIL + lo;
             const u32 d = b0 >> 5, sft = b0 & 31u;
             if (val) {
                 atomicOr(&img[fi * fstride + d], val << sft);
@@ -245,7 +278,7 @@ DEV u32 traceback_part(const char* dec, u32* scratch, u32* img, u32 fstride, u32
             }
         }
     }
-    return __shfl(E_out, (int)(fi * 16u));  // block 0 of the frame ends at step ts
+    return __shfl(P_out, (int)(fi * 16u));  // block 0 of the frame ends at step ts
 }
 
 __global__ __launch_bounds__(64) void vit_pk_kernel(const uint8_t* __restrict__ sym, uint8_t* __restrict__ out,
@@ -350,7 +383,7 @@ __global__ __launch_bounds__(64) void vit_pk_kernel(const uint8_t* __restrict__ 
     u32* scratch = reinterpret_cast<u32*>(tab) + lane * KW;
     // LDS-resident blocks [R, nblk): steps [max(16R,6), T); every frame ends in state 0
     u32 t_hi = R * 16u;  // steps >= t_hi are done
-    u32 E_next = traceback_part(dec, scratch, img, fstride, lane, t_hi > VIT_TAIL ? t_hi : VIT_TAIL, t_T, T_max, R, 0u);
+    u32 E_next = traceback_part(dec, scratch, img, fstride, lane, t_hi > VIT_TAIL ? t_hi : VIT_TAIL, t_T, T_max, R, P_ZERO);
     // register-resident blocks, 16 at a time from the top
     for (u32 g1 = R; g1 > 0;) {
         const u32 g0 = g1 > DUMP_GROUP ? g1 - DUMP_GROUP : 0u;  // group = blocks [g0, g1)
@@ -362,7 +395,7 @@ __global__ __launch_bounds__(64) void vit_pk_kernel(const uint8_t* __restrict__ 
         const u32 ts = g0 ? g0 * 16u : VIT_TAIL, tend = g1 * 16u;
         const u32 te = t_T < tend ? t_T : tend, te_max = T_max < tend ? T_max : tend;
         // a frame that reaches beyond this group continues from the state the later part ended in
-        E_next = traceback_part(dec, scratch, img, fstride, lane, ts, te, te_max, g0, t_T > tend ? E_next : 0u);
+        E_next = traceback_part(dec, scratch, img, fstride, lane, ts, te, te_max, g0, t_T > tend ? E_next : P_ZERO);
         g1 = g0;
     }
     __syncthreads();

@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libviterbi.so")
+LIB_PATH = os.environ.get("VITERBI_AMD_LIB") or os.path.join(_HERE, "libviterbi.so")  # env: kernel experiments
 MAX_FRAMEBITS = 9216
 TAIL = 6
 

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/profiles_<tag>/ into the committed summaries under profiles/."""
+import collections
+import csv
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", "profiles_" + tag)
+dst = os.path.join(root, "profiles")
+KERNEL = "vit_pk_kernel"
+
+lines = []
+bench = None
+with open(os.path.join(src, "bench.json")) as f:
+    for line in f:
+        if line.startswith("{"):
+            bench = json.loads(line)
+with open(os.path.join(dst, "%s_bench.json" % tag), "w") as f:
+    json.dump(bench, f, indent=1)
+lines.append("# %s — bench.py (default flags) on MI355X\n" % tag)
+lines.append("value %.1f %s, ms_per_step %.4f, roofline %s\n" % (bench["value"], bench["unit"], bench["ms_per_step"], json.dumps(bench["roofline"])))
+lines.append("cpu_baseline %s\nparity %s\n" % (json.dumps(bench.get("cpu_baseline")), json.dumps(bench.get("parity"))))
+
+lines.append("\n# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu   (kernel_stats.csv, top rows)\n")
+with open(os.path.join(src, "kernel_stats.csv")) as f:
+    rows = list(csv.DictReader(f))
+avg_ns = None
+for r in rows[:6]:
+    lines.append("%-60.60s calls=%s avg_ns=%s total_ns=%s pct=%s\n" % (r["Name"], r["Calls"], r["AverageNs"], r["TotalDurationNs"], r["Percentage"]))
+    if KERNEL in r["Name"]:
+        avg_ns = float(r["AverageNs"])
+
+tot = {}
+meta = {}
+for p in ("p1", "p2", "p3"):
+    fn = os.path.join(src, "pmc_%s.csv" % p)
+    if not os.path.exists(fn):
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(fn)):
+        if KERNEL in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta = {k: r[k] for k in ("VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Workgroup_Size", "Grid_Size") if k in r}
+    for k, v in agg.items():
+        tot[k] = sum(v) / len(v)
+lines.append("\n# rocprofv3 --pmc ... (separate passes), mean per launch of %s; dispatch %s\n" % (KERNEL, json.dumps(meta)))
+for k, v in sorted(tot.items()):
+    lines.append("%-22s %.6g\n" % (k, v))
+alg = bench["roofline"]["algorithmic_bytes_per_launch"]
+if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
+    # MI355X_MICROARCH.md: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly 1/2 of a
+    # coalesced streaming read -> double it.  Our read volume is known (the symbol buffer), which calibrates it.
+    fetch = 2.0 * tot["FETCH_SIZE"] * 1024.0
+    write = tot["WRITE_SIZE"] * 1024.0
+    traffic = fetch + write
+    lines.append("\nHBM traffic per launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 = %.4g + %.4g = %.4g B; algorithmic %.4g B; ratio %.3f\n"
+                 % (fetch, write, traffic, alg, traffic / alg))
+    with open(os.path.join(dst, "pmc_traffic.json"), "w") as f:
+        json.dump({"round": tag, "kernel": KERNEL, "hbm_bytes_per_launch": int(traffic), "fetch_bytes_corrected": int(fetch),
+                   "write_bytes": int(write), "algorithmic_bytes_per_launch": alg,
+                   "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units; "
+                             "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a streaming read)"}, f, indent=1)
+if avg_ns:
+    lines.append("kernel avg (rocprof) %.1f us vs bench HIP-event kernel_ms %.4f ms\n" % (avg_ns / 1e3, bench["roofline"]["kernel_ms"]))
+if "SQ_WAVES" in tot:
+    w = tot["SQ_WAVES"]
+    lines.append("per wave: VALU %.0f  SALU %.0f  LDS %.0f  wave-cycles(quad) %.0f\n" % (
+        tot.get("SQ_INSTS_VALU", 0) / w, tot.get("SQ_INSTS_SALU", 0) / w, tot.get("SQ_INSTS_LDS", 0) / w, tot.get("SQ_WAVE_CYCLES", 0) / w))
+open(os.path.join(dst, "%s_rocprof_summary.txt" % tag), "w").writelines(lines)
+print("".join(lines))

@@ -58,7 +58,6 @@ DEV u32 avg4(u32 a, u32 b) { return __builtin_amdgcn_lerp(a, b, 0x01010101u); } 
 constexpr int TAB_BYTES = 2048;  // 16 steps x 2 pairs x 8 triples x (M,MM) 8 B
 constexpr int DEC_BLOCK = 512;   // 16 steps of decisions: 64 lanes x 8 B
 constexpr u32 HI = 0xFF00FF00u;  // +0xFF00 in both halves
-constexpr int KW = 8;            // traceback bit words per lane (BL <= 256)
 
 struct Lanes {
     u32 toff[5];  // LDS byte offset of this lane's (M,MM) entry for phase rho
@@ -177,17 +176,28 @@ constexpr u32 VREG_BLOCKS = 32;  // decision blocks that can stay in VGPRs (2 x 
 
 constexpr u32 DUMP_GROUP = 16;   // register blocks are dumped to LDS 16 at a time
 
-// Number of leading 16-step blocks whose decisions stay in registers; the remaining
-// nblk - R (>= 16 when R > 0) live in LDS, whose region is then reused for the dumps.
+// LDS layout of one wave: [ dec: Ld blocks x 512 B ][ tabregion ].  The LAST block's decisions are
+// written where the (by then dead) branch-metric table starts, right behind dec, so a FIC frame
+// needs 16 x 512 + 2048 = 10 KB and 16 waves fit a CU.  Blocks [0,R) stay in VGPRs.
+//   nblk <= 17 : R = 0,                 Ld = nblk - 1
+//   else       : R = min(32, nblk - 17), Ld = nblk - R - 1  (>= 16 = one dump group)
 __host__ __device__ inline u32 pk_reg_blocks(u32 nblk) {
-    if (nblk <= DUMP_GROUP) return 0;
-    const u32 r = nblk - DUMP_GROUP;
+    if (nblk <= DUMP_GROUP + 1u) return 0;
+    const u32 r = nblk - (DUMP_GROUP + 1u);
     return r < VREG_BLOCKS ? r : VREG_BLOCKS;
 }
-__host__ __device__ inline u32 pk_lds_blocks(u32 nblk) {
-    const u32 r = pk_reg_blocks(nblk);
-    const u32 l = nblk - r;
-    return (r && l < DUMP_GROUP) ? DUMP_GROUP : l;
+__host__ __device__ inline u32 pk_img_stride(u32 maxfb) { return ((maxfb + 31u) >> 5) + 2u; }  // dwords per frame
+__host__ __device__ inline u32 pk_scratch_words(u32 maxfb) {
+    // words per lane of traceback bit scratch: the longest part is the LDS tail or a 256-step register group
+    const u32 nblk = (maxfb + VIT_TAIL + 15u) >> 4;
+    const u32 tail = (nblk - pk_reg_blocks(nblk)) * 16u;
+    const u32 span = tail > 256u ? tail : 256u;
+    const u32 bl = 5u * ((span + 79u) / 80u);
+    return (bl + 31u) >> 5;
+}
+__host__ __device__ inline u32 pk_tabregion_bytes(u32 maxfb) {
+    const u32 need = DEC_BLOCK + 64u * 4u * pk_scratch_words(maxfb) + 16u * pk_img_stride(maxfb);
+    return need > (u32)TAB_BYTES ? ((need + 15u) & ~15u) : (u32)TAB_BYTES;
 }
 
 // ---- traceback -------------------------------------------------------------------------------
@@ -283,11 +293,10 @@ DEV u32 traceback_part(const char* dec, u32* scratch, u32* img, u32 fstride, u32
 
 __global__ __launch_bounds__(64) void vit_pk_kernel(const uint8_t* __restrict__ sym, uint8_t* __restrict__ out,
                                                     const vit_frame_desc* __restrict__ desc,
-                                                    u32 framebits_uniform, long long nframes, u32 img_bytes) {
+                                                    u32 framebits_uniform, long long nframes, u32 dec_bytes) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    char* tab = lds;                                         // [tau][pair][c] -> (M,MM); later traceback scratch
-    u32* img = reinterpret_cast<u32*>(lds + TAB_BYTES);      // output bit image, 4 frames
-    char* dec = lds + TAB_BYTES + img_bytes;                 // [block - R][lane] -> (acc0, acc1)
+    char* dec = lds;              // [block - R][lane] -> (acc0, acc1); the last block spills into tab
+    char* tab = lds + dec_bytes;  // [tau][pair][c] -> (M,MM); after the ACS: last block, scratch, image
     const u32 lane = threadIdx.x;
     const long long f0 = (long long)blockIdx.x * 4;
 
@@ -316,8 +325,7 @@ __global__ __launch_bounds__(64) void vit_pk_kernel(const uint8_t* __restrict__ 
     if (maxfb == 0) return;
     const u32 nblk = (maxfb + VIT_TAIL + 15u) >> 4;
     const u32 R = pk_reg_blocks(nblk);  // blocks [0,R) in VGPRs, [R,nblk) in LDS
-    const u32 fstride = ((maxfb + 31u) >> 5) + 2u;  // image dwords per frame (+ slack for the shifted spill)
-    for (u32 i = lane; i < 4u * fstride; i += 64u) img[i] = 0;
+    const u32 fstride = pk_img_stride(maxfb);  // image dwords per frame (+ slack for the shifted spill)
 
     // ---- ACS-phase lane constants ----
     const u32 l5 = lane & 31u, pair = lane >> 5;
@@ -380,7 +388,10 @@ __global__ __launch_bounds__(64) void vit_pk_kernel(const uint8_t* __restrict__ 
     const u32 t_fb = fi == 0 ? fbits[0] : fi == 1 ? fbits[1] : fi == 2 ? fbits[2] : fbits[3];
     const u32 t_T = t_fb ? t_fb + VIT_TAIL : 0u;  // steps of this lane's frame
     const u32 T_max = maxfb + VIT_TAIL;
-    u32* scratch = reinterpret_cast<u32*>(tab) + lane * KW;
+    const u32 nsw = pk_scratch_words(maxfb);
+    u32* scratch = reinterpret_cast<u32*>(tab + DEC_BLOCK) + lane * nsw;            // traceback bit words
+    u32* img = reinterpret_cast<u32*>(tab + DEC_BLOCK) + 64u * nsw;                  // output bit image, 4 frames
+    for (u32 i = lane; i < 4u * fstride; i += 64u) img[i] = 0;
     // LDS-resident blocks [R, nblk): steps [max(16R,6), T); every frame ends in state 0
     u32 t_hi = R * 16u;  // steps >= t_hi are done
     u32 E_next = traceback_part(dec, scratch, img, fstride, lane, t_hi > VIT_TAIL ? t_hi : VIT_TAIL, t_T, T_max, R, P_ZERO);
@@ -417,13 +428,13 @@ __global__ __launch_bounds__(64) void vit_pk_kernel(const uint8_t* __restrict__ 
     }
 }
 
-constexpr u32 PK_MAX_FRAMEBITS = 4096;  // BL <= 256 bits of traceback scratch per lane
+constexpr u32 PK_MAX_FRAMEBITS = 4096;
 
-u32 pk_img_bytes(u32 max_framebits) { return ((4u * (((max_framebits + 31u) >> 5) + 2u) * 4u) + 15u) & ~15u; }
-size_t pk_lds_bytes(u32 max_framebits) {
+u32 pk_dec_bytes(u32 max_framebits) {
     const u32 nblk = (max_framebits + VIT_TAIL + 15u) >> 4;
-    return (size_t)TAB_BYTES + pk_img_bytes(max_framebits) + (size_t)pk_lds_blocks(nblk) * DEC_BLOCK;
+    return (nblk - pk_reg_blocks(nblk) - 1u) * DEC_BLOCK;
 }
+size_t pk_lds_bytes(u32 max_framebits) { return (size_t)pk_dec_bytes(max_framebits) + pk_tabregion_bytes(max_framebits); }
 
 }  // namespace
 
@@ -446,6 +457,6 @@ hipError_t vit_launch_pk(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_d
     const long long groups = (nframes + 3) / 4;
     if (groups > 0x7FFFFFFFLL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(vit_pk_kernel, dim3((unsigned)groups), dim3(64), pk_lds_bytes(max_framebits), stream, d_sym,
-                       d_out, d_desc, framebits, (long long)nframes, pk_img_bytes(max_framebits));
+                       d_out, d_desc, framebits, (long long)nframes, pk_dec_bytes(max_framebits));
     return hipGetLastError();
 }

@@ -55,7 +55,7 @@ DEV u32 bfi(u32 mask, u32 a, u32 b) {
 }
 DEV u32 avg4(u32 a, u32 b) { return __builtin_amdgcn_lerp(a, b, 0x01010101u); }  // pavgb x4
 
-constexpr int TAB_BYTES = 2048;  // 16 steps x 2 pairs x 8 triples x (M,MM) 8 B
+constexpr int TAB_BYTES = 2048;  // 32 steps x 2 pairs x 8 triples x M (4 B); 63-M is one v_sub in the ACS
 constexpr int DEC_BLOCK = 512;   // 16 steps of decisions: 64 lanes x 8 B
 constexpr u32 HI = 0xFF00FF00u;  // +0xFF00 in both halves
 
@@ -104,8 +104,10 @@ struct Consts {
 
 // One trellis step for 4 frames (deconvolve.cpp:352-374 in packed u16 form).
 template <int RHO, bool ODD>
-DEV void acs_step(u32& A, u32& B, u32& acc0, u32& acc1, uint2 mt, u32 lane, const Consts& C) {
-    const us2 a = U(A), b = U(B), M = U(mt.x), MM = U(mt.y);
+DEV void acs_step(u32& A, u32& B, u32& acc0, u32& acc1, u32 mt, u32 lane, const Consts& C) {
+    // 63 - M per half as ONE 32-bit subtract.  Odd steps: M <= 63, no borrow.  Even steps carry the
+    // +0xFF00 bias: (0xFE3F - M') mod 2^16 per half; the low half always borrows, hence 0xFE40 on top.
+    const us2 a = U(A), b = U(B), M = U(mt), MM = U((ODD ? 0x003F003Fu : 0xFE40FE3Fu) - mt);
     const us2 m0 = __builtin_elementwise_add_sat(a, M), m1 = __builtin_elementwise_add_sat(b, MM);
     const us2 m2 = __builtin_elementwise_add_sat(a, MM), m3 = __builtin_elementwise_add_sat(b, M);
     us2 n0 = __builtin_elementwise_min(m0, m1), n1 = __builtin_elementwise_min(m2, m3);
@@ -134,7 +136,7 @@ struct Steps {
     static DEV void run(u32& A, u32& B, u32& acc0, u32& acc1, const char* tab, const Lanes& L, u32 lane,
                         const Consts& C) {
         constexpr int RHO = (V + J) % 5;
-        const uint2 mt = *reinterpret_cast<const uint2*>(tab + L.toff[RHO] + J * 128);
+        const u32 mt = *reinterpret_cast<const u32*>(tab + L.toff[RHO] + J * 64);
         acs_step<RHO, (J & 1) != 0>(A, B, acc0, acc1, mt, lane, C);
         Steps<V, J + 1>::run(A, B, acc0, acc1, tab, L, lane, C);
     }
@@ -144,31 +146,35 @@ struct Steps<V, 16> {
     static DEV void run(u32&, u32&, u32&, u32&, const char*, const Lanes&, u32, const Consts&) {}
 };
 
-// Four of the 8 pavgb-tree metrics of one frame-step: s = its 4 soft symbols (bytes).
+// The 8 pavgb-tree metrics of one frame-step: s = its 4 soft symbols (bytes), ns = ~s.
 // metric(c) = avg(avg(s0^B0, s1^B1), avg(s2^B2, s3^B0)) >> 2 for the mask triple
-// c = b0 | b1<<1 | b2<<2 (b3 = b0); returns the 4 metrics with b2 = qsel's half as bytes b0 + 2*b1.
-DEV u32 met4(u32 s, u32 qsel) {
-    const u32 r0 = __builtin_amdgcn_perm(s, s, 0x00000000u) ^ 0xFF00FF00u;  // s0 ^ B0, byte pos = b0 + 2*b1
-    const u32 r1 = __builtin_amdgcn_perm(s, s, 0x01010101u) ^ 0xFFFF0000u;  // s1 ^ B1
-    const u32 r2 = __builtin_amdgcn_perm(s, s, 0x02020202u) ^ 0xFFFF0000u;  // s2 ^ B2, byte pos = b0 + 2*b2
-    const u32 r3 = __builtin_amdgcn_perm(s, s, 0x03030303u) ^ 0xFF00FF00u;  // s3 ^ B0
+// c = b0 | b1<<1 | b2<<2 (b3 = b0); bytes of lo = c 0..3, bytes of hi = c 4..7.
+// x ^ 0xFF = ~x, so one v_perm_b32 over {s, ~s} yields the four masked variants of a symbol.
+DEV void met8(u32 s, u32& lo, u32& hi) {
+    const u32 ns = ~s;
+    const u32 r0 = __builtin_amdgcn_perm(ns, s, 0x04000400u);  // s0 ^ B0, byte pos = b0 + 2*b1
+    const u32 r1 = __builtin_amdgcn_perm(ns, s, 0x05050101u);  // s1 ^ B1
+    const u32 r2 = __builtin_amdgcn_perm(ns, s, 0x06060202u);  // s2 ^ B2, byte pos = b0 + 2*b2
+    const u32 r3 = __builtin_amdgcn_perm(ns, s, 0x07030703u);  // s3 ^ B0
     const u32 P = avg4(r0, r1), Q = avg4(r2, r3);
-    const u32 q = __builtin_amdgcn_perm(Q, Q, qsel);  // Q(b0, b2) aligned to P's (b0,b1)
-    return (avg4(P, q) >> 2) & 0x3F3F3F3Fu;
+    const u32 qlo = __builtin_amdgcn_perm(Q, Q, 0x01000100u);  // Q(b0, b2=0) aligned to P's (b0,b1)
+    const u32 qhi = __builtin_amdgcn_perm(Q, Q, 0x03020302u);  // b2 = 1
+    lo = (avg4(P, qlo) >> 2) & 0x3F3F3F3Fu;
+    hi = (avg4(P, qhi) >> 2) & 0x3F3F3F3Fu;
 }
 
-// Pre-pass for 16 steps: lane = (tau = lane>>2, pair = (lane>>1)&1, b2 = lane&1) computes, for
-// step t0+tau, the (M, 63-M) entries of the four triples with its b2 for BOTH frames of its pair
-// and writes its 32 table bytes; no cross-lane traffic.
-DEV void prepass(u32 sa, u32 sb, char* tab, u32 lane, u32 qsel, const u32 (&sel)[4]) {
-    const u32 a = met4(sa, qsel), b = met4(sb, qsel);  // frame half 0 / half 1 of the ACS registers
-    const u32 am = 0x3F3F3F3Fu - a, bm = 0x3F3F3F3Fu - b;
+// Pre-pass for 32 steps: lane = (tau = lane>>1, pair = lane&1) computes the 8 branch metrics of both
+// frames of its pair for step t0+tau and writes its 32 table bytes (M only); no cross-lane traffic.
+DEV void prepass(u32 sa, u32 sb, char* tab, u32 lane, const u32 (&sel)[4]) {
+    u32 alo, ahi, blo, bhi;
+    met8(sa, alo, ahi);  // frame half 0 (low 16 bits of the ACS registers)
+    met8(sb, blo, bhi);  // frame half 1
     uint4* dst = reinterpret_cast<uint4*>(tab + lane * 32);
     // sel[k]: byte k of the half-0 word, byte k of the half-1 word, and 0xFF high bytes (+0xFF00) on even steps
-    dst[0] = make_uint4(__builtin_amdgcn_perm(b, a, sel[0]), __builtin_amdgcn_perm(bm, am, sel[0]),
-                        __builtin_amdgcn_perm(b, a, sel[1]), __builtin_amdgcn_perm(bm, am, sel[1]));
-    dst[1] = make_uint4(__builtin_amdgcn_perm(b, a, sel[2]), __builtin_amdgcn_perm(bm, am, sel[2]),
-                        __builtin_amdgcn_perm(b, a, sel[3]), __builtin_amdgcn_perm(bm, am, sel[3]));
+    dst[0] = make_uint4(__builtin_amdgcn_perm(blo, alo, sel[0]), __builtin_amdgcn_perm(blo, alo, sel[1]),
+                        __builtin_amdgcn_perm(blo, alo, sel[2]), __builtin_amdgcn_perm(blo, alo, sel[3]));
+    dst[1] = make_uint4(__builtin_amdgcn_perm(bhi, ahi, sel[0]), __builtin_amdgcn_perm(bhi, ahi, sel[1]),
+                        __builtin_amdgcn_perm(bhi, ahi, sel[2]), __builtin_amdgcn_perm(bhi, ahi, sel[3]));
 }
 
 typedef u32 v32u __attribute__((ext_vector_type(32)));
@@ -335,18 +341,17 @@ __global__ __launch_bounds__(64) void vit_pk_kernel(const uint8_t* __restrict__ 
         const u32 i = ((l5 << rho) | (l5 >> (5 - rho))) & 31u;  // butterfly index rol5(l, rho)
         const u32 i0 = i & 1u, i1 = (i >> 1) & 1u, i2 = (i >> 2) & 1u, i3 = (i >> 3) & 1u, i4 = (i >> 4) & 1u;
         const u32 c = (i1 ^ i2 ^ i4) | ((i0 ^ i1 ^ i2) << 1) | ((i0 ^ i3) << 2);  // parity((2i)&poly_j), const.asm:27-63
-        L.toff[rho] = pair * 64u + c * 8u;
+        L.toff[rho] = pair * 32u + c * 4u;
     }
     Consts C;
     C.hi = HI;
     asm volatile("" : "+v"(C.hi));  // keep it in a VGPR
-    // ---- pre-pass lane constants: lane = (tau = lane>>2, pair pp = (lane>>1)&1, b2 = lane&1) ----
-    const u32 tau = lane >> 2, pp = (lane >> 1) & 1u;
+    // ---- pre-pass lane constants: lane = (tau = lane>>1, pair pp = lane&1) ----
+    const u32 tau = lane >> 1, pp = lane & 1u;
     const u32 a_fb = pp ? fbits[2] : fbits[0], b_fb = pp ? fbits[3] : fbits[1];
     const u32 a_T = a_fb ? a_fb + VIT_TAIL : 0u, b_T = b_fb ? b_fb + VIT_TAIL : 0u;
     const u32* a_sym = reinterpret_cast<const u32*>(sym + (pp ? soff[2] : soff[0]));
     const u32* b_sym = reinterpret_cast<const u32*>(sym + (pp ? soff[3] : soff[1]));
-    const u32 qsel = (lane & 1u) ? 0x03020302u : 0x01000100u;
     u32 sel[4];
     {
         const u32 hb = (tau & 1u) ? 0x0C000C00u : 0x0D000D00u;  // even step: 0xFF high bytes (= +0xFF00)
@@ -361,27 +366,32 @@ __global__ __launch_bounds__(64) void vit_pk_kernel(const uint8_t* __restrict__ 
     u32 sa = tau < a_T ? a_sym[tau] : 0u, sb = tau < b_T ? b_sym[tau] : 0u;
     u32 v = 0;
     for (u32 blk = 0; blk < nblk; blk++) {
-        prepass(sa, sb, tab, lane, qsel, sel);
-        const u32 tn = (blk + 1) * 16u + tau;
-        sa = tn < a_T ? a_sym[tn] : 0u;  // prefetch the next block's symbols
-        sb = tn < b_T ? b_sym[tn] : 0u;
-        __syncthreads();
+        if ((blk & 1u) == 0) {
+            if (blk) __syncthreads();  // every lane is done reading the previous 32-step table
+            prepass(sa, sb, tab, lane, sel);
+            const u32 tn = (blk + 2) * 16u + tau;
+            sa = tn < a_T ? a_sym[tn] : 0u;  // prefetch the next 32 steps' symbols
+            sb = tn < b_T ? b_sym[tn] : 0u;
+            __syncthreads();
+        }
+        const char* th = tab + (blk & 1u) * 1024u;
         switch (v) {
-            case 0: Steps<0, 0>::run(A, B, acc0, acc1, tab, L, lane, C); break;
-            case 1: Steps<1, 0>::run(A, B, acc0, acc1, tab, L, lane, C); break;
-            case 2: Steps<2, 0>::run(A, B, acc0, acc1, tab, L, lane, C); break;
-            case 3: Steps<3, 0>::run(A, B, acc0, acc1, tab, L, lane, C); break;
-            default: Steps<4, 0>::run(A, B, acc0, acc1, tab, L, lane, C); break;
+            case 0: Steps<0, 0>::run(A, B, acc0, acc1, th, L, lane, C); break;
+            case 1: Steps<1, 0>::run(A, B, acc0, acc1, th, L, lane, C); break;
+            case 2: Steps<2, 0>::run(A, B, acc0, acc1, th, L, lane, C); break;
+            case 3: Steps<3, 0>::run(A, B, acc0, acc1, th, L, lane, C); break;
+            default: Steps<4, 0>::run(A, B, acc0, acc1, th, L, lane, C); break;
         }
         v = v == 4 ? 0 : v + 1;
         if (blk < R) {
             r0[blk] = acc0;  // s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off
             r1[blk] = acc1;
         } else {
+            if (blk + 1u == nblk) __syncthreads();  // the last block lands on the table: all reads done first
             *reinterpret_cast<uint2*>(dec + (blk - R) * DEC_BLOCK + lane * 8) = make_uint2(acc0, acc1);
         }
-        __syncthreads();  // table is rewritten by the next pre-pass
     }
+    __syncthreads();
 
     // ---- traceback, last part first: lane = (frame fi, block q) ----
     const u32 fi = lane >> 4;

@@ -216,7 +216,58 @@ __host__ __device__ inline u32 pk_tabregion_bytes(u32 maxfb) {
 // P = (31-l)<<3 | (1-n)<<2: inserting the stored bit unchanged, and 252 - P is the byte
 // offset of the word to read.  State 0 is P = 252.
 constexpr u32 P_ZERO = 252u;
-constexpr u32 TB_WARM = 30u;  // warm-up steps a speculative block starts above its own range
+constexpr u32 TB_WARM = 30u;  // warm-up steps (multiple of 5) a speculative block starts above its own range
+
+// One step back for every active lane.  JJ = 3 + j is the position of lane bit j inside P.
+//   word  = dec[(t>>4) - slot0][pair][l][n]            (base folds pair, slot0 and the 252)
+//   kb    = bit (t & 15) + 16*half of it               (= NOT decision)
+//   P     = P with bit JJ := kb, bit 2 := old bit JJ
+template <int JJ>
+DEV void tb_step(u32& P, u32& kb, u32 t, const char* base, u32 halfshift) {
+    const u32 w = *reinterpret_cast<const u32*>(base + ((t << 5) & ~511u) - P);
+    kb = (w >> ((t & 15u) | halfshift)) & 1u;
+    const u32 b = (P >> JJ) & 1u;
+    P = (P & ~((1u << JJ) | 4u)) | (kb << JJ) | (b << 2);
+}
+
+// Runs block-relative indices i = i_from .. i_to (downwards; i_from + 1 and i_to are multiples of 5
+// so that the phase of every unrolled position is static: j(i) = (j0 - i) mod 5, JA = j(i_from)).
+// Lanes take part while `on` and i <= i_start.  RECORD: collect kb bits of index i into words
+// (bit i&31 of word i>>5), flushed to scratch when a word is complete.
+template <bool RECORD, int JA>
+DEV void tb_loop(u32& P, u32* scratch, int i_from, int i_to, bool on, u32 i_start, u32 tbase, const char* base,
+                 u32 halfshift) {
+    u32 cur = 0;
+    for (int i = i_from; i >= i_to; i -= 5) {
+#define TB_ONE(K)                                                                  \
+    {                                                                              \
+        const int ii = i - (K);                                                    \
+        u32 kb = 0;                                                                \
+        if (on && (u32)ii <= i_start) tb_step<3 + (JA + (K)) % 5>(P, kb, tbase + (u32)ii, base, halfshift); \
+        if (RECORD) {                                                              \
+            cur |= kb << (ii & 31);                                                \
+            if ((ii & 31) == 0) {                                                  \
+                if (on) scratch[ii >> 5] = cur;                                    \
+                cur = 0;                                                           \
+            }                                                                      \
+        }                                                                          \
+    }
+        TB_ONE(0) TB_ONE(1) TB_ONE(2) TB_ONE(3) TB_ONE(4)
+#undef TB_ONE
+    }
+}
+template <bool RECORD>
+DEV void tb_run(u32& P, u32* scratch, int i_from, int i_to, bool on, u32 i_start, u32 tbase, const char* base,
+                u32 halfshift, u32 j0) {
+    // i_from % 5 == 4  ->  j(i_from) = (j0 - 4) mod 5 = (j0 + 1) % 5
+    switch ((j0 + 1u) % 5u) {
+        case 0: tb_loop<RECORD, 0>(P, scratch, i_from, i_to, on, i_start, tbase, base, halfshift); break;
+        case 1: tb_loop<RECORD, 1>(P, scratch, i_from, i_to, on, i_start, tbase, base, halfshift); break;
+        case 2: tb_loop<RECORD, 2>(P, scratch, i_from, i_to, on, i_start, tbase, base, halfshift); break;
+        case 3: tb_loop<RECORD, 3>(P, scratch, i_from, i_to, on, i_start, tbase, base, halfshift); break;
+        default: tb_loop<RECORD, 4>(P, scratch, i_from, i_to, on, i_start, tbase, base, halfshift); break;
+    }
+}
 
 // One traceback part over steps [ts, te) of every frame (te per lane's frame, te_max uniform),
 // decisions of block b at dec + (b - slot0)*512.  Lane = (frame fi = lane>>4, block q = lane&15)
@@ -243,39 +294,21 @@ DEV u32 traceback_part(const char* dec, u32* scratch, u32* img, u32 fstride, u32
     const u32 halfshift = (fi & 1u) * 16u;
     const u32 j0 = (4u + 5u - ((ts + 5u - 1u) % 5u)) % 5u;  // j of block-relative index 0: 4 - ((ts-1) mod 5)
 
-    u32 P = fixed ? P_top : P_ZERO, P_in = P, P_end = P, P_out = P_top;
-    bool need = has_work;
-    int i_from = (int)i_warm;
-    for (int pass = 0; pass < 18; pass++) {
-        u32 cur = 0;
-        // j(i) = (j0 - i) mod 5
-        u32 jj = 3u + (j0 + 5u - ((u32)i_from % 5u)) % 5u;  // bit position of lane bit j inside P
-        for (int i = i_from; i >= 0; i--) {
-            if (i == (int)BL - 1) P_end = (need && i_start >= BL - 1u) ? P : P_end;
-            if (need && (u32)i <= i_start) {
-                const u32 t = tbase + (u32)i;
-                const u32 w = *reinterpret_cast<const u32*>(base + ((t << 5) & ~511u) - P);
-                const u32 kb = (w >> ((t & 15u) | halfshift)) & 1u;  // stored bit = NOT decision
-                const u32 b = (P >> jj) & 1u;
-                P = (P & ~((1u << jj) | 4u)) | (kb << jj) | (b << 2);
-                if (i < (int)BL) cur |= kb << (i & 31);  // warm-up steps leave no bits
-            }
-            if (i < (int)BL && (i & 31) == 0) {
-                if (need) scratch[i >> 5] = cur;
-                cur = 0;
-            }
-            jj = jj == 7u ? 3u : jj + 1u;
-        }
-        if (need) P_out = P;
-        if (pass == 0) P_in = P_end;  // what the warm-up trace passed through at the block's top
+    u32 P = fixed ? P_top : P_ZERO, P_out = P_top;
+    // pass 0: warm-up (no bits kept) then the block itself
+    tb_run<false>(P, scratch, (int)i_warm, (int)BL, has_work, i_start, tbase, base, halfshift, j0);
+    u32 P_in = P;  // position the trace passed through at the block's top (meaningless for short top blocks)
+    tb_run<true>(P, scratch, (int)BL - 1, 0, has_work, i_start, tbase, base, halfshift, j0);
+    if (has_work) P_out = P;
+    for (int pass = 0; pass < 17; pass++) {
         const u32 nxt = __shfl_down(P_out, 1);
         const u32 new_in = (q < q_top) ? nxt : P_top;
         const bool changed = has_work && !fixed && new_in != P_in;
-        need = changed;
         if (!__any(changed)) break;
-        P_in = changed ? new_in : P_in;
+        if (changed) P_in = new_in;
         P = new_in;
-        i_from = (int)BL - 1;
+        tb_run<true>(P, scratch, (int)BL - 1, 0, changed, BL - 1u, tbase, base, halfshift, j0);
+        if (changed) P_out = P;
     }
     // decoded bit index of step t is t - 6 (chainback skips the 6 tail decisions); decoded bit = NOT stored bit
     if (has_work) {

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the headline bench): BASELINE configs 3 and 5 and per-length rates.
+Prints one JSON object per line.  Run on the GPU box."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import _vitpkg  # noqa: E402
+from bench import make_frames  # noqa: E402
+
+V = _vitpkg.load_package()
+O = _vitpkg.load_oracle()
+dev = torch.device("cuda", 0)
+V.initialize()
+
+
+def timeit(fn, steps=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(steps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / steps
+
+
+# ---- uniform lengths ----
+for fb in (288, 768, 1536, 2304, 3072, 4096, 6912):
+    n = max(4096, min(65536, (768 * 65536) // fb) // 4 * 4)
+    sym = make_frames(n, fb, seed=fb, device=dev)
+    out = torch.zeros((n, fb // 8), dtype=torch.uint8, device=dev)
+    ms = timeit(lambda: V.decode_batch_dev(sym, out, fb, n))
+    # parity on a sample
+    k = min(n, 512)
+    want = O.decode_batch(fb, sym[:k].cpu().numpy(), nthreads=16)
+    ok = bool(np.array_equal(out[:k].cpu().numpy(), want))
+    print(json.dumps({"case": "uniform", "framebits": fb, "frames": n, "ms": round(ms, 4),
+                      "Mbit_s": round(n * fb / ms / 1e3, 1), "parity_sample_ok": ok}), flush=True)
+
+# ---- config 3: mixed MSC lengths 96*m, m in 3..72, batch 32768, descriptor table ----
+rng = np.random.default_rng(3)
+n = 32768
+fbs = 96 * rng.integers(3, 73, n)
+for label, order in (("as drawn", np.arange(n)), ("sorted by length", np.argsort(fbs, kind="stable"))):
+    f = fbs[order]
+    desc, sym_bytes, out_bytes = V.make_descs(f.tolist())
+    sym = torch.randint(0, 256, (sym_bytes,), dtype=torch.uint8, device=dev)
+    out = torch.zeros(out_bytes, dtype=torch.uint8, device=dev)
+    d_desc = torch.from_numpy(desc.view(np.uint8)).to(dev)
+    mx = int(f.max())
+    ms = timeit(lambda: V.decode_varlen_dev(sym, out, d_desc, n, mx), steps=5, warm=1)
+    # parity on a sample of frames
+    idx = rng.choice(n, 64, replace=False)
+    sh, oh = sym.cpu().numpy(), out.cpu().numpy()
+    ok = True
+    for i in idx:
+        fb = int(f[i]); so = int(desc["sym_offset"][i]); oo = int(desc["out_offset"][i])
+        ok &= bool(np.array_equal(O.decode_batch(fb, sh[so:so + O.sym_len(fb)])[0], oh[oo:oo + fb // 8]))
+    print(json.dumps({"case": "config3 mixed 288..6912", "order": label, "frames": n, "ms": round(ms, 3),
+                      "Mbit_s": round(float(f.sum()) / ms / 1e3, 1), "parity_sample_ok": ok}), flush=True)
+
+# ---- config 5: RS(120,110) superframes ----
+for rsdims in (24, 12, 4):
+    nsf = 16384
+    rng = np.random.default_rng(rsdims)
+    base_n = 64
+    p = np.empty((base_n, 120, rsdims), np.uint8)
+    for s in range(base_n):
+        for j in range(rsdims):
+            cw = O.rs_encode(rng.integers(0, 256, 110, dtype=np.uint8))
+            ne = int(rng.choice([0, 0, 0, 0, 1, 2, 3, 5, 6]))
+            pos = rng.choice(120, ne, replace=False)
+            cw[pos] ^= rng.integers(1, 256, ne, dtype=np.uint8)
+            p[s, :, j] = cw
+    p = p.reshape(base_n, -1)
+    ret_ref, out_ref = O.rs_check_batch(p, rsdims)
+    d_p = torch.from_numpy(p).to(dev).repeat(nsf // base_n, 1).contiguous()
+    d_out = torch.zeros((nsf, 110 * rsdims), dtype=torch.uint8, device=dev)
+    d_ret = torch.zeros(nsf, dtype=torch.int32, device=dev)
+    ms = timeit(lambda: V.rs_batch_dev(d_p, d_out, d_ret, rsdims, nsf))
+    ok = bool(np.array_equal(d_ret[:base_n].cpu().numpy(), ret_ref)) and \
+        bool(np.array_equal(d_out[:base_n].cpu().numpy(), out_ref))
+    print(json.dumps({"case": "config5 RS", "rsdims": rsdims, "superframes": nsf, "ms": round(ms, 4),
+                      "GB_s_in_plus_out": round(nsf * 230 * rsdims / ms / 1e6, 1),
+                      "superframes_per_s": round(nsf / ms * 1e3), "parity_ok": ok}), flush=True)

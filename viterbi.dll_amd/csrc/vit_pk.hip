@@ -103,7 +103,7 @@ struct Consts {
 };
 
 // One trellis step for 4 frames (deconvolve.cpp:352-374 in packed u16 form).
-template <int RHO, bool ODD>
+template <int RHO, bool ODD, bool HIST>
 DEV void acs_step(u32& A, u32& B, u32& acc0, u32& acc1, u32 mt, u32 lane, const Consts& C) {
     // 63 - M per half as ONE 32-bit subtract.  Odd steps: M <= 63, no borrow.  Even steps carry the
     // +0xFF00 bias: (0xFE3F - M') mod 2^16 per half; the low half always borrows, hence 0xFE40 on top.
@@ -112,11 +112,13 @@ DEV void acs_step(u32& A, u32& B, u32& acc0, u32& acc1, u32 mt, u32 lane, const 
     const us2 m2 = __builtin_elementwise_add_sat(a, MM), m3 = __builtin_elementwise_add_sat(b, M);
     us2 n0 = __builtin_elementwise_min(m0, m1), n1 = __builtin_elementwise_min(m2, m3);
     // sign(m0-m1) = 1  <=>  m0 < m1  <=>  decision bit 0 (tie -> decision 1)
-    const us2 x01 = m0 - m1, x23 = m2 - m3;
-    // history: plain 32-bit shift (2 cycles) + v_bfi (4); the bfi also discards the bit that the
-    // 32-bit shift carries from the upper half into bit 15
-    acc0 = bfi(0x80008000u, W(x01), acc0 >> 1);
-    acc1 = bfi(0x80008000u, W(x23), acc1 >> 1);
+    if constexpr (HIST) {
+        const us2 x01 = m0 - m1, x23 = m2 - m3;
+        // history: plain 32-bit shift (2 cycles) + v_bfi (4); the bfi also discards the bit that the
+        // 32-bit shift carries from the upper half into bit 15
+        acc0 = bfi(0x80008000u, W(x01), acc0 >> 1);
+        acc1 = bfi(0x80008000u, W(x23), acc1 >> 1);
+    }
     if constexpr (ODD) {
         // Renormalize256: state 0 (lane 0 of the pair, register N0) > 150 -> psubusb 63.
         // z = m + 0xFF00 per half.  z + 0x8069 has bit 15 set iff m >= 151; done as ONE 32-bit add:
@@ -131,20 +133,30 @@ DEV void acs_step(u32& A, u32& B, u32& acc0, u32& acc1, u32 mt, u32 lane, const 
     exchange<4 - RHO>(A, B, W(n0), W(n1), lane);
 }
 
-template <int V, int J>
+template <int V, int J, bool HIST>
 struct Steps {
     static DEV void run(u32& A, u32& B, u32& acc0, u32& acc1, const char* tab, const Lanes& L, u32 lane,
                         const Consts& C) {
         constexpr int RHO = (V + J) % 5;
         const u32 mt = *reinterpret_cast<const u32*>(tab + L.toff[RHO] + J * 64);
-        acs_step<RHO, (J & 1) != 0>(A, B, acc0, acc1, mt, lane, C);
-        Steps<V, J + 1>::run(A, B, acc0, acc1, tab, L, lane, C);
+        acs_step<RHO, (J & 1) != 0, HIST>(A, B, acc0, acc1, mt, lane, C);
+        Steps<V, J + 1, HIST>::run(A, B, acc0, acc1, tab, L, lane, C);
     }
 };
-template <int V>
-struct Steps<V, 16> {
+template <int V, bool HIST>
+struct Steps<V, 16, HIST> {
     static DEV void run(u32&, u32&, u32&, u32&, const char*, const Lanes&, u32, const Consts&) {}
 };
+template <bool HIST>
+DEV void steps16(u32 v, u32& A, u32& B, u32& acc0, u32& acc1, const char* th, const Lanes& L, u32 lane, const Consts& C) {
+    switch (v) {
+        case 0: Steps<0, 0, HIST>::run(A, B, acc0, acc1, th, L, lane, C); break;
+        case 1: Steps<1, 0, HIST>::run(A, B, acc0, acc1, th, L, lane, C); break;
+        case 2: Steps<2, 0, HIST>::run(A, B, acc0, acc1, th, L, lane, C); break;
+        case 3: Steps<3, 0, HIST>::run(A, B, acc0, acc1, th, L, lane, C); break;
+        default: Steps<4, 0, HIST>::run(A, B, acc0, acc1, th, L, lane, C); break;
+    }
+}
 
 // The 8 pavgb-tree metrics of one frame-step: s = its 4 soft symbols (bytes), ns = ~s.
 // metric(c) = avg(avg(s0^B0, s1^B1), avg(s2^B2, s3^B0)) >> 2 for the mask triple
@@ -181,29 +193,58 @@ typedef u32 v32u __attribute__((ext_vector_type(32)));
 constexpr u32 VREG_BLOCKS = 32;  // decision blocks that can stay in VGPRs (2 x 32 dwords)
 
 constexpr u32 DUMP_GROUP = 16;   // register blocks are dumped to LDS 16 at a time
+constexpr u32 SEG_BLOCKS = VREG_BLOCKS + DUMP_GROUP + 1u;  // 49 blocks = 784 steps: one FIC frame
 
-// LDS layout of one wave: [ dec: Ld blocks x 512 B ][ tabregion ].  The LAST block's decisions are
-// written where the (by then dead) branch-metric table starts, right behind dec, so a FIC frame
-// needs 16 x 512 + 2048 = 10 KB and 16 waves fit a CU.  Blocks [0,R) stay in VGPRs.
-//   nblk <= 17 : R = 0,                 Ld = nblk - 1
-//   else       : R = min(32, nblk - 17), Ld = nblk - R - 1  (>= 16 = one dump group)
-__host__ __device__ inline u32 pk_reg_blocks(u32 nblk) {
-    if (nblk <= DUMP_GROUP + 1u) return 0;
-    const u32 r = nblk - (DUMP_GROUP + 1u);
+// Decision history of ONE SEGMENT (<= 49 blocks).  Blocks [0,R) of the segment stay in VGPRs, the
+// other nb - R in LDS: Ld of them in the `dec` region, the LAST one where the (by then dead)
+// branch-metric table starts, right behind dec - so a FIC frame needs 16 x 512 + 2048 = 10 KB of
+// LDS and 16 waves fit a CU.
+//   nb <= 17 : R = 0,                Ld = nb - 1
+//   else     : R = min(32, nb - 17), Ld = nb - R - 1  (>= 16 = one dump group)
+// Frames longer than a segment are decoded in segments: a forward pass without history saves the
+// path metrics at every segment boundary (512 B), then the segments are recomputed with history
+// and traced back last to first.
+__host__ __device__ inline u32 pk_reg_blocks(u32 nb) {
+    if (nb <= DUMP_GROUP + 1u) return 0;
+    const u32 r = nb - (DUMP_GROUP + 1u);
     return r < VREG_BLOCKS ? r : VREG_BLOCKS;
 }
 __host__ __device__ inline u32 pk_img_stride(u32 maxfb) { return ((maxfb + 31u) >> 5) + 2u; }  // dwords per frame
 __host__ __device__ inline u32 pk_scratch_words(u32 maxfb) {
-    // words per lane of traceback bit scratch: the longest part is the LDS tail or a 256-step register group
-    const u32 nblk = (maxfb + VIT_TAIL + 15u) >> 4;
+    // words per lane of traceback bit scratch: the longest part is a segment's LDS tail (<= 17 blocks)
+    // or a 256-step register group -> BL <= 20 for full segments; short frames are all "tail"
+    u32 nblk = (maxfb + VIT_TAIL + 15u) >> 4;
+    if (nblk > SEG_BLOCKS) nblk = SEG_BLOCKS;
     const u32 tail = (nblk - pk_reg_blocks(nblk)) * 16u;
     const u32 span = tail > 256u ? tail : 256u;
     const u32 bl = 5u * ((span + 79u) / 80u);
     return (bl + 31u) >> 5;
 }
-__host__ __device__ inline u32 pk_tabregion_bytes(u32 maxfb) {
-    const u32 need = DEC_BLOCK + 64u * 4u * pk_scratch_words(maxfb) + 16u * pk_img_stride(maxfb);
-    return need > (u32)TAB_BYTES ? ((need + 15u) & ~15u) : (u32)TAB_BYTES;
+struct PkLayout {
+    u32 dec_bytes;  // tab starts here
+    u32 cp_off;     // checkpoints (nseg - 1) x 512 B, 0 if none
+    u32 img_off;    // output bit image
+    u32 total;
+};
+__host__ __device__ inline PkLayout pk_layout(u32 maxfb) {
+    const u32 nblk = (maxfb + VIT_TAIL + 15u) >> 4;
+    const u32 nseg = (nblk + SEG_BLOCKS - 1u) / SEG_BLOCKS;
+    const u32 nb = nblk < SEG_BLOCKS ? nblk : SEG_BLOCKS;
+    PkLayout l;
+    l.dec_bytes = (nb - pk_reg_blocks(nb) - 1u) * DEC_BLOCK;
+    const u32 scratch = 64u * 4u * pk_scratch_words(maxfb), img = 16u * pk_img_stride(maxfb);
+    if (nseg == 1) {  // the image can live in the dead table region too
+        u32 tabregion = DEC_BLOCK + scratch + img;
+        tabregion = tabregion > (u32)TAB_BYTES ? ((tabregion + 15u) & ~15u) : (u32)TAB_BYTES;
+        l.cp_off = 0;
+        l.img_off = l.dec_bytes + DEC_BLOCK + scratch;
+        l.total = l.dec_bytes + tabregion;
+    } else {  // table stays live across segments: checkpoints and image get their own space
+        l.cp_off = l.dec_bytes + TAB_BYTES;
+        l.img_off = l.cp_off + (nseg - 1u) * 512u;
+        l.total = l.img_off + ((img + 15u) & ~15u);
+    }
+    return l;
 }
 
 // ---- traceback -------------------------------------------------------------------------------
@@ -330,12 +371,16 @@ DEV u32 traceback_part(const char* dec, u32* scratch, u32* img, u32 fstride, u32
     return __shfl(P_out, (int)(fi * 16u));  // block 0 of the frame ends at step ts
 }
 
-__global__ __launch_bounds__(64) void vit_pk_kernel(const uint8_t* __restrict__ sym, uint8_t* __restrict__ out,
+// MULTI = false: every frame fits one segment (the FIC fast path; the phase loop folds away).
+template <bool MULTI>
+__global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict__ sym, uint8_t* __restrict__ out,
                                                     const vit_frame_desc* __restrict__ desc,
-                                                    u32 framebits_uniform, long long nframes, u32 dec_bytes) {
+                                                    u32 framebits_uniform, long long nframes, PkLayout lay) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    char* dec = lds;              // [block - R][lane] -> (acc0, acc1); the last block spills into tab
-    char* tab = lds + dec_bytes;  // [tau][pair][c] -> (M,MM); after the ACS: last block, scratch, image
+    char* dec = lds;                  // [block - R][lane] -> (acc0, acc1); the last block spills into tab
+    char* tab = lds + lay.dec_bytes;  // [tau][pair][c] -> M; after a segment's ACS: last block, scratch
+    uint2* cp = reinterpret_cast<uint2*>(lds + lay.cp_off);  // (A,B) at the start of segments 1..nseg-1
+    u32* img = reinterpret_cast<u32*>(lds + lay.img_off);    // output bit image, 4 frames
     const u32 lane = threadIdx.x;
     const long long f0 = (long long)blockIdx.x * 4;
 
@@ -363,8 +408,9 @@ __global__ __launch_bounds__(64) void vit_pk_kernel(const uint8_t* __restrict__ 
     }
     if (maxfb == 0) return;
     const u32 nblk = (maxfb + VIT_TAIL + 15u) >> 4;
-    const u32 R = pk_reg_blocks(nblk);  // blocks [0,R) in VGPRs, [R,nblk) in LDS
+    const u32 nseg = MULTI ? (nblk + SEG_BLOCKS - 1u) / SEG_BLOCKS : 1u;
     const u32 fstride = pk_img_stride(maxfb);  // image dwords per frame (+ slack for the shifted spill)
+    const u32 T_max = maxfb + VIT_TAIL;
 
     // ---- ACS-phase lane constants ----
     const u32 l5 = lane & 31u, pair = lane >> 5;
@@ -391,66 +437,99 @@ __global__ __launch_bounds__(64) void vit_pk_kernel(const uint8_t* __restrict__ 
 #pragma unroll
         for (int k = 0; k < 4; k++) sel[k] = hb | (0x00040000u + 0x00010001u * k);  // byte k of half 0 / half 1
     }
-
-    // ---- ACS over all blocks ----
-    u32 A = l5 == 0 ? 0u : 0x003F003Fu, B = 0x003F003Fu;  // const.asm:19-25 (0-based, step 0 is even)
-    u32 acc0 = 0, acc1 = 0;
-    v32u r0, r1;  // register-resident decisions of blocks [0,R)
-    u32 sa = tau < a_T ? a_sym[tau] : 0u, sb = tau < b_T ? b_sym[tau] : 0u;
-    u32 v = 0;
-    for (u32 blk = 0; blk < nblk; blk++) {
-        if ((blk & 1u) == 0) {
-            if (blk) __syncthreads();  // every lane is done reading the previous 32-step table
-            prepass(sa, sb, tab, lane, sel);
-            const u32 tn = (blk + 2) * 16u + tau;
-            sa = tn < a_T ? a_sym[tn] : 0u;  // prefetch the next 32 steps' symbols
-            sb = tn < b_T ? b_sym[tn] : 0u;
-            __syncthreads();
-        }
-        const char* th = tab + (blk & 1u) * 1024u;
-        switch (v) {
-            case 0: Steps<0, 0>::run(A, B, acc0, acc1, th, L, lane, C); break;
-            case 1: Steps<1, 0>::run(A, B, acc0, acc1, th, L, lane, C); break;
-            case 2: Steps<2, 0>::run(A, B, acc0, acc1, th, L, lane, C); break;
-            case 3: Steps<3, 0>::run(A, B, acc0, acc1, th, L, lane, C); break;
-            default: Steps<4, 0>::run(A, B, acc0, acc1, th, L, lane, C); break;
-        }
-        v = v == 4 ? 0 : v + 1;
-        if (blk < R) {
-            r0[blk] = acc0;  // s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off
-            r1[blk] = acc1;
-        } else {
-            if (blk + 1u == nblk) __syncthreads();  // the last block lands on the table: all reads done first
-            *reinterpret_cast<uint2*>(dec + (blk - R) * DEC_BLOCK + lane * 8) = make_uint2(acc0, acc1);
-        }
-    }
-    __syncthreads();
-
-    // ---- traceback, last part first: lane = (frame fi, block q) ----
+    // ---- traceback lane constants: lane = (frame fi, block q) ----
     const u32 fi = lane >> 4;
     const u32 t_fb = fi == 0 ? fbits[0] : fi == 1 ? fbits[1] : fi == 2 ? fbits[2] : fbits[3];
     const u32 t_T = t_fb ? t_fb + VIT_TAIL : 0u;  // steps of this lane's frame
-    const u32 T_max = maxfb + VIT_TAIL;
     const u32 nsw = pk_scratch_words(maxfb);
-    u32* scratch = reinterpret_cast<u32*>(tab + DEC_BLOCK) + lane * nsw;            // traceback bit words
-    u32* img = reinterpret_cast<u32*>(tab + DEC_BLOCK) + 64u * nsw;                  // output bit image, 4 frames
-    for (u32 i = lane; i < 4u * fstride; i += 64u) img[i] = 0;
-    // LDS-resident blocks [R, nblk): steps [max(16R,6), T); every frame ends in state 0
-    u32 t_hi = R * 16u;  // steps >= t_hi are done
-    u32 E_next = traceback_part(dec, scratch, img, fstride, lane, t_hi > VIT_TAIL ? t_hi : VIT_TAIL, t_T, T_max, R, P_ZERO);
-    // register-resident blocks, 16 at a time from the top
-    for (u32 g1 = R; g1 > 0;) {
-        const u32 g0 = g1 > DUMP_GROUP ? g1 - DUMP_GROUP : 0u;  // group = blocks [g0, g1)
+    u32* scratch = reinterpret_cast<u32*>(tab + DEC_BLOCK) + lane * nsw;  // traceback bit words
+
+    const u32 A_init = l5 == 0 ? 0u : 0x003F003Fu, B_init = 0x003F003Fu;  // const.asm:19-25 (0-based, step 0 is even)
+    u32 A = A_init, B = B_init;
+    u32 acc0 = 0, acc1 = 0;
+    v32u r0, r1;          // register-resident decisions of the current segment's blocks [0,R)
+    u32 P_next = P_ZERO;  // per frame: traceback position at the start of the segment above
+
+    // Phases: forward over segments 0..nseg-1 (history only in the last one), then the earlier
+    // segments again, last to first, recomputed from their checkpoints with history.
+    const u32 nphase = 2u * nseg - 1u;
+    for (u32 ph = 0; ph < nphase; ph++) {
+        const bool fwd = ph < nseg;
+        const u32 seg = fwd ? ph : 2u * nseg - 2u - ph;
+        const bool hist = !fwd || seg + 1u == nseg;
+        const u32 b0 = seg * SEG_BLOCKS, b1 = (b0 + SEG_BLOCKS < nblk) ? b0 + SEG_BLOCKS : nblk;
+        const u32 nb = b1 - b0, R = pk_reg_blocks(nb);
+        if (!fwd) {
+            if (seg) {
+                const uint2 c = cp[(seg - 1u) * 64u + lane];
+                A = c.x;
+                B = c.y;
+            } else {
+                A = A_init;
+                B = B_init;
+            }
+        }
+        // ---- ACS over the segment's blocks ----
+        {
+            const u32 t0 = b0 * 16u + tau;
+            u32 sa = t0 < a_T ? a_sym[t0] : 0u, sb = t0 < b_T ? b_sym[t0] : 0u;
+            u32 v = b0 % 5u;
+            for (u32 rb = 0; rb < nb; rb++) {
+                if ((rb & 1u) == 0) {
+                    __syncthreads();  // every lane is done with the previous table / scratch
+                    prepass(sa, sb, tab, lane, sel);
+                    const u32 tn = (b0 + rb + 2u) * 16u + tau;
+                    sa = tn < a_T ? a_sym[tn] : 0u;  // prefetch the next 32 steps' symbols
+                    sb = tn < b_T ? b_sym[tn] : 0u;
+                    __syncthreads();
+                }
+                const char* th = tab + (rb & 1u) * 1024u;
+                if (hist) {
+                    steps16<true>(v, A, B, acc0, acc1, th, L, lane, C);
+                    if (rb < R) {
+                        r0[rb] = acc0;  // s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off
+                        r1[rb] = acc1;
+                    } else {
+                        if (rb + 1u == nb) __syncthreads();  // the last block lands on the table: all reads done first
+                        *reinterpret_cast<uint2*>(dec + (rb - R) * DEC_BLOCK + lane * 8) = make_uint2(acc0, acc1);
+                    }
+                } else {
+                    steps16<false>(v, A, B, acc0, acc1, th, L, lane, C);
+                }
+                v = v == 4 ? 0 : v + 1;
+            }
+        }
+        if (fwd && seg + 1u < nseg) cp[seg * 64u + lane] = make_uint2(A, B);
+        if (!hist) continue;
         __syncthreads();
+        if (fwd)  // first traceback of this group: clear the image (it may alias the table region)
+            for (u32 i = lane; i < 4u * fstride; i += 64u) img[i] = 0;
+
+        // ---- traceback of the segment, last part first ----
+        const u32 seg_end = b1 * 16u;  // steps >= seg_end are done; frames reaching beyond continue from P_next
+        const u32 te_seg = t_T < seg_end ? t_T : seg_end, te_seg_max = T_max < seg_end ? T_max : seg_end;
+        const u32 P_top_seg = t_T > seg_end ? P_next : P_ZERO;
+        // LDS-resident blocks [b0+R, b1)
+        const u32 t_lo = (b0 + R) * 16u;
+        u32 P_part = traceback_part(dec, scratch, img, fstride, lane, t_lo > VIT_TAIL ? t_lo : VIT_TAIL, te_seg,
+                                    te_seg_max, b0 + R, P_top_seg);
+        // register-resident blocks, 16 at a time from the top
+        for (u32 g1 = R; g1 > 0;) {
+            const u32 g0 = g1 > DUMP_GROUP ? g1 - DUMP_GROUP : 0u;  // group = segment blocks [g0, g1)
+            __syncthreads();
 #pragma unroll
-        for (u32 b = 0; b < VREG_BLOCKS; b++)
-            if (b >= g0 && b < g1) *reinterpret_cast<uint2*>(dec + (b - g0) * DEC_BLOCK + lane * 8) = make_uint2(r0[b], r1[b]);
-        __syncthreads();
-        const u32 ts = g0 ? g0 * 16u : VIT_TAIL, tend = g1 * 16u;
-        const u32 te = t_T < tend ? t_T : tend, te_max = T_max < tend ? T_max : tend;
-        // a frame that reaches beyond this group continues from the state the later part ended in
-        E_next = traceback_part(dec, scratch, img, fstride, lane, ts, te, te_max, g0, t_T > tend ? E_next : P_ZERO);
-        g1 = g0;
+            for (u32 b = 0; b < VREG_BLOCKS; b++)
+                if (b >= g0 && b < g1)
+                    *reinterpret_cast<uint2*>(dec + (b - g0) * DEC_BLOCK + lane * 8) = make_uint2(r0[b], r1[b]);
+            __syncthreads();
+            const u32 tsg = (b0 + g0) ? (b0 + g0) * 16u : VIT_TAIL, tend = (b0 + g1) * 16u;
+            const u32 te = t_T < tend ? t_T : tend, te_max = T_max < tend ? T_max : tend;
+            // a frame that reaches beyond this group continues from the position the later part ended in
+            const u32 P_top = t_T > tend ? P_part : P_ZERO;
+            P_part = traceback_part(dec, scratch, img, fstride, lane, tsg, te, te_max, b0 + g0, P_top);
+            g1 = g0;
+        }
+        P_next = P_part;
     }
     __syncthreads();
 
@@ -471,19 +550,13 @@ __global__ __launch_bounds__(64) void vit_pk_kernel(const uint8_t* __restrict__ 
     }
 }
 
-constexpr u32 PK_MAX_FRAMEBITS = 4096;
-
-u32 pk_dec_bytes(u32 max_framebits) {
-    const u32 nblk = (max_framebits + VIT_TAIL + 15u) >> 4;
-    return (nblk - pk_reg_blocks(nblk) - 1u) * DEC_BLOCK;
-}
-size_t pk_lds_bytes(u32 max_framebits) { return (size_t)pk_dec_bytes(max_framebits) + pk_tabregion_bytes(max_framebits); }
+constexpr u32 PK_MAX_FRAMEBITS = VIT_MAX_FRAMEBITS;
 
 }  // namespace
 
 bool vit_pk_supported(uint32_t max_framebits) {
     return max_framebits >= 8 && max_framebits <= PK_MAX_FRAMEBITS && (max_framebits % 8u) == 0 &&
-           pk_lds_bytes(max_framebits) <= 160u * 1024u;
+           pk_layout(max_framebits).total <= 160u * 1024u;
 }
 
 hipError_t vit_launch_pk(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_desc* d_desc, uint32_t framebits,
@@ -492,14 +565,23 @@ hipError_t vit_launch_pk(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_d
     if (!vit_pk_supported(max_framebits)) return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vit_pk_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vit_pk_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(vit_pk_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const long long groups = (nframes + 3) / 4;
     if (groups > 0x7FFFFFFFLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(vit_pk_kernel, dim3((unsigned)groups), dim3(64), pk_lds_bytes(max_framebits), stream, d_sym,
-                       d_out, d_desc, framebits, (long long)nframes, pk_dec_bytes(max_framebits));
+    const PkLayout lay = pk_layout(max_framebits);
+    const bool multi = ((max_framebits + VIT_TAIL + 15u) >> 4) > SEG_BLOCKS;
+    if (multi)
+        hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)groups), dim3(64), lay.total, stream, d_sym, d_out,
+                           d_desc, framebits, (long long)nframes, lay);
+    else
+        hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)groups), dim3(64), lay.total, stream, d_sym, d_out,
+                           d_desc, framebits, (long long)nframes, lay);
     return hipGetLastError();
 }

@@ -372,8 +372,11 @@ DEV u32 traceback_part(const char* dec, u32* scratch, u32* img, u32 fstride, u32
 }
 
 // MULTI = false: every frame fits one segment (the FIC fast path; the phase loop folds away).
+#ifndef VIT_MULTI_WAVES
+#define VIT_MULTI_WAVES 2  /* 190 VGPRs without spills; measured faster than 3 or 4 with spills */
+#endif
 template <bool MULTI>
-__global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict__ sym, uint8_t* __restrict__ out,
+__global__ __launch_bounds__(64, MULTI ? VIT_MULTI_WAVES : 4) void vit_pk_kernel(const uint8_t* __restrict__ sym, uint8_t* __restrict__ out,
                                                     const vit_frame_desc* __restrict__ desc,
                                                     u32 framebits_uniform, long long nframes, PkLayout lay) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -437,15 +440,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
 #pragma unroll
         for (int k = 0; k < 4; k++) sel[k] = hb | (0x00040000u + 0x00010001u * k);  // byte k of half 0 / half 1
     }
-    // ---- traceback lane constants: lane = (frame fi, block q) ----
-    const u32 fi = lane >> 4;
-    const u32 t_fb = fi == 0 ? fbits[0] : fi == 1 ? fbits[1] : fi == 2 ? fbits[2] : fbits[3];
-    const u32 t_T = t_fb ? t_fb + VIT_TAIL : 0u;  // steps of this lane's frame
-    const u32 nsw = pk_scratch_words(maxfb);
-    u32* scratch = reinterpret_cast<u32*>(tab + DEC_BLOCK) + lane * nsw;  // traceback bit words
-
-    const u32 A_init = l5 == 0 ? 0u : 0x003F003Fu, B_init = 0x003F003Fu;  // const.asm:19-25 (0-based, step 0 is even)
-    u32 A = A_init, B = B_init;
+    u32 A = l5 == 0 ? 0u : 0x003F003Fu, B = 0x003F003Fu;  // const.asm:19-25 (0-based, step 0 is even)
     u32 acc0 = 0, acc1 = 0;
     v32u r0, r1;          // register-resident decisions of the current segment's blocks [0,R)
     u32 P_next = P_ZERO;  // per frame: traceback position at the start of the segment above
@@ -453,7 +448,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
     // Phases: forward over segments 0..nseg-1 (history only in the last one), then the earlier
     // segments again, last to first, recomputed from their checkpoints with history.
     const u32 nphase = 2u * nseg - 1u;
-    for (u32 ph = 0; ph < nphase; ph++) {
+    auto phase = [&](const u32 ph) {
         const bool fwd = ph < nseg;
         const u32 seg = fwd ? ph : 2u * nseg - 2u - ph;
         const bool hist = !fwd || seg + 1u == nseg;
@@ -465,8 +460,8 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
                 A = c.x;
                 B = c.y;
             } else {
-                A = A_init;
-                B = B_init;
+                A = (lane & 31u) == 0 ? 0u : 0x003F003Fu;
+                B = 0x003F003Fu;
             }
         }
         // ---- ACS over the segment's blocks ----
@@ -500,12 +495,16 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
             }
         }
         if (fwd && seg + 1u < nseg) cp[seg * 64u + lane] = make_uint2(A, B);
-        if (!hist) continue;
+        if (!hist) return;
         __syncthreads();
         if (fwd)  // first traceback of this group: clear the image (it may alias the table region)
             for (u32 i = lane; i < 4u * fstride; i += 64u) img[i] = 0;
 
-        // ---- traceback of the segment, last part first ----
+        // ---- traceback of the segment, last part first: lane = (frame fi, block q) ----
+        const u32 fi = lane >> 4;
+        const u32 t_fb = fi == 0 ? fbits[0] : fi == 1 ? fbits[1] : fi == 2 ? fbits[2] : fbits[3];
+        const u32 t_T = t_fb ? t_fb + VIT_TAIL : 0u;  // steps of this lane's frame
+        u32* scratch = reinterpret_cast<u32*>(tab + DEC_BLOCK) + lane * pk_scratch_words(maxfb);  // traceback bit words
         const u32 seg_end = b1 * 16u;  // steps >= seg_end are done; frames reaching beyond continue from P_next
         const u32 te_seg = t_T < seg_end ? t_T : seg_end, te_seg_max = T_max < seg_end ? T_max : seg_end;
         const u32 P_top_seg = t_T > seg_end ? P_next : P_ZERO;
@@ -530,6 +529,11 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
             g1 = g0;
         }
         P_next = P_part;
+    };
+    if constexpr (MULTI) {
+        for (u32 ph = 0; ph < nphase; ph++) phase(ph);
+    } else {
+        phase(0);
     }
     __syncthreads();
 

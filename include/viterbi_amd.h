@@ -125,6 +125,13 @@ int vit_rs_batch_dev(const uint8_t *d_p, uint8_t *d_out, int32_t *d_ret,
 int vit_rs_batch_host(const uint8_t *h_p, uint8_t *h_out, int32_t *h_ret,
                       uint32_t RSDims, int64_t nsf);
 
+/* DAB+ superframe path: nsf superframes, each = 5 consecutive frames of
+ * framebits = 192*RSDims bits in d_symbols_u8.  Decodes the 5*nsf frames into d_work
+ * (nsf*120*RSDims bytes, device) -- five decoded frames ARE the RS input block p[j + k*RSDims] --
+ * and runs the batched RScheckSuperframe on it.  Both kernels are enqueued on `stream`. */
+int vit_dabplus_superframes_dev(const uint8_t *d_symbols_u8, uint8_t *d_work, uint8_t *d_rs_out,
+                                int32_t *d_ret, uint32_t RSDims, int64_t nsf, void *stream);
+
 /* Kernel selection for experiments/tests: 0 = auto, 1 = wave-per-frame
  * reference kernel, 2 = packed 4-frames-per-wave kernel.  Returns the old
  * value.  Affects later vit_decode_* calls of the whole process. */

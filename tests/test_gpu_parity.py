@@ -233,6 +233,44 @@ def test_rscheck_export(V, O, torch_cuda):
     assert V.lib().RScheckSuperframe(None, 0, 10, None) == -1
 
 
+def test_dabplus_superframe_pipeline(V, O, torch_cuda):
+    """BASELINE config 5 in small: RS-coded payload -> mother code -> noise -> deconvolve x5 ->
+    RScheckSuperframe, GPU pipeline against the oracle's two stages."""
+    torch = torch_cuda
+    rsdims, nsf = 12, 24
+    fb = 192 * rsdims
+    rng = np.random.default_rng(12)
+    syms = np.empty((nsf * 5, O.sym_len(fb)), np.uint8)
+    state = 1234567
+    for s in range(nsf):
+        block = np.empty((120, rsdims), np.uint8)
+        for j in range(rsdims):
+            cw = O.rs_encode(rng.integers(0, 256, 110, dtype=np.uint8))
+            ne = int(rng.choice([0, 0, 1, 3, 5, 6, 7]))  # post-Viterbi symbol errors, some uncorrectable
+            pos = rng.choice(120, ne, replace=False)
+            cw[pos] ^= rng.integers(1, 256, ne, dtype=np.uint8)
+            block[:, j] = cw
+        bits = np.unpackbits(block.reshape(-1)).reshape(5, fb)
+        for k in range(5):
+            hard = O.encode(bits[k]).astype(np.float64)
+            noise = rng.normal(0.0, 1.0, hard.size)
+            v = 127.5 + 32.0 * ((hard * 2 - 1) * 1.6 + noise)  # mild noise: a few residual bit errors at most
+            syms[s * 5 + k] = np.clip(v.astype(np.int64), 0, 255).astype(np.uint8)
+    dec_ref = O.decode_batch(fb, syms, nthreads=8).reshape(nsf, 120 * rsdims)
+    init = np.full((nsf, 110 * rsdims), 0x3C, np.uint8)
+    ret_ref, out_ref = O.rs_check_batch(dec_ref, rsdims, out_init=init)
+    assert (ret_ref == -1).any() and (ret_ref >= 0).any()
+    d_sym = torch.from_numpy(syms).cuda()
+    d_work = torch.zeros((nsf, 120 * rsdims), dtype=torch.uint8, device="cuda")
+    d_out = torch.from_numpy(init.copy()).cuda()
+    d_ret = torch.zeros(nsf, dtype=torch.int32, device="cuda")
+    V.dabplus_superframes_dev(d_sym, d_work, d_out, d_ret, rsdims, nsf)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_work.cpu().numpy(), dec_ref)
+    assert np.array_equal(d_ret.cpu().numpy(), ret_ref)
+    assert np.array_equal(d_out.cpu().numpy(), out_ref)
+
+
 # ---- BASELINE sizes through size-independent properties ----------------------------
 
 def test_full_size_fic_batch_properties(V, O, torch_cuda):

@@ -22,7 +22,7 @@ EXPORTS = [
     "deconvolve", "initialize", "RScheckSuperframe", "RSCheckSuperframe", "GetCPUCaps", "WakeUpYMM",
     "vit_last_error", "vit_device_count", "vit_set_kernel", "vit_decode_batch_dev",
     "vit_decode_batch_dev_u32", "vit_decode_varlen_dev", "vit_pack_symbols_dev",
-    "vit_decode_batch_host", "vit_rs_batch_dev", "vit_rs_batch_host",
+    "vit_decode_batch_host", "vit_rs_batch_dev", "vit_rs_batch_host", "vit_dabplus_superframes_dev",
 ]
 
 
@@ -74,6 +74,7 @@ def lib():
         L.vit_decode_batch_host.argtypes = [vp, vp, C.c_uint32, C.c_int64]
         L.vit_rs_batch_dev.argtypes = [vp, vp, vp, C.c_uint32, C.c_int64, vp]
         L.vit_rs_batch_host.argtypes = [vp, vp, vp, C.c_uint32, C.c_int64]
+        L.vit_dabplus_superframes_dev.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_int64, vp]
         _lib = L
     return _lib
 
@@ -191,6 +192,13 @@ def rs_batch_dev(d_p, d_out, d_ret, RSDims, nsf, stream=None):
     _check(lib().vit_rs_batch_dev(C.c_void_p(d_p.data_ptr()), C.c_void_p(d_out.data_ptr()),
                                   C.c_void_p(d_ret.data_ptr()), RSDims, nsf, _stream_ptr(stream)),
            "vit_rs_batch_dev")
+
+
+def dabplus_superframes_dev(d_symbols_u8, d_work, d_rs_out, d_ret, RSDims, nsf, stream=None):
+    """decode 5*nsf frames of 192*RSDims bits, then RScheckSuperframe on every group of five"""
+    _check(lib().vit_dabplus_superframes_dev(C.c_void_p(d_symbols_u8.data_ptr()), C.c_void_p(d_work.data_ptr()),
+                                             C.c_void_p(d_rs_out.data_ptr()), C.c_void_p(d_ret.data_ptr()),
+                                             RSDims, nsf, _stream_ptr(stream)), "vit_dabplus_superframes_dev")
 
 
 def make_descs(framebits_list, sym_align=4):

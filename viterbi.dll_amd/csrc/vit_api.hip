@@ -326,6 +326,22 @@ int vit_rs_batch_dev(const uint8_t* d_p, uint8_t* d_out, int32_t* d_ret, uint32_
     return VIT_OK;
 }
 
+int vit_dabplus_superframes_dev(const uint8_t* d_symbols_u8, uint8_t* d_work, uint8_t* d_rs_out, int32_t* d_ret,
+                                uint32_t RSDims, int64_t nsf, void* stream) {
+    if (hip_device_ready() != VIT_OK) return VIT_ERR_NO_DEVICE;
+    const uint64_t framebits = 192ull * RSDims;  // 24 ms frame of an RSDims*8 kbit/s sub-channel
+    if (RSDims == 0 || framebits > VIT_MAX_FRAMEBITS || nsf < 0 ||
+        (nsf > 0 && (!d_symbols_u8 || !d_work || !d_rs_out || !d_ret))) {
+        set_err("vit_dabplus_superframes_dev: bad arguments (RSDims=%u)", RSDims);
+        return VIT_ERR_ARG;
+    }
+    if (nsf == 0) return VIT_OK;
+    int rc = launch_decode(d_symbols_u8, d_work, nullptr, (uint32_t)framebits, (uint32_t)framebits, 5 * nsf,
+                           (hipStream_t)stream);
+    if (rc != VIT_OK) return rc;
+    return vit_rs_batch_dev(d_work, d_rs_out, d_ret, RSDims, nsf, stream);
+}
+
 int vit_rs_batch_host(const uint8_t* h_p, uint8_t* h_out, int32_t* h_ret, uint32_t RSDims, int64_t nsf) {
     if (nsf < 0 || RSDims > 65535u || (nsf > 0 && (!h_ret || (RSDims > 0 && (!h_p || !h_out))))) {
         set_err("vit_rs_batch_host: bad arguments");

@@ -73,6 +73,9 @@ struct Lanes {
 // DPP and v_cmp instruction holds the SIMD for 4 cycles per wave, v_permlane*_swap for 8, and
 // v_cndmask_b32 through VCC for ~22.  So for J < 4 the partner values travel through the LDS
 // crossbar (ds_swizzle: no VALU slot, no LDS memory) and two v_cndmask_b32_e64 pick them up.
+#ifndef VIT_SWZ_ALL
+#define VIT_SWZ_ALL 0
+#endif
 template <int J>
 DEV void exchange(u32& A, u32& B, u32 N0, u32 N1, u32 lane) {
     if constexpr (J == 4) {
@@ -80,11 +83,11 @@ DEV void exchange(u32& A, u32& B, u32 N0, u32 N1, u32 lane) {
         auto r = __builtin_amdgcn_permlane16_swap(N0, N1, false, false);
         A = r[0];
         B = r[1];
-    } else if constexpr (J == 3) {
+    } else if constexpr (J == 3 && !VIT_SWZ_ALL) {
         // masked DPP moves stay in the VALU (10 cycles incl. one copy) and keep LDS latency off this step
         A = __builtin_amdgcn_update_dpp(N0, N1, 0x128 /*row_ror:8*/, 0xF, 0xC, false);
         B = __builtin_amdgcn_update_dpp(N1, N0, 0x128, 0xF, 0x3, false);
-    } else if constexpr (J == 2) {
+    } else if constexpr (J == 2 && !VIT_SWZ_ALL) {
         A = __builtin_amdgcn_update_dpp(N0, N1, 0x114 /*row_shr:4*/, 0xF, 0xA, false);
         B = __builtin_amdgcn_update_dpp(N1, N0, 0x104 /*row_shl:4*/, 0xF, 0x5, false);
     } else {

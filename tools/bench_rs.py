@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""RS(120,110) batch micro-benchmark (config 5's second stage)."""
+import json, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import _vitpkg
+V = _vitpkg.load_package(); O = _vitpkg.load_oracle(); V.initialize()
+dev = torch.device("cuda", 0)
+rsdims = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+nsf = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+mode = sys.argv[3] if len(sys.argv) > 3 else "mixed"
+rng = np.random.default_rng(rsdims); base_n = 64
+p = np.empty((base_n, 120, rsdims), np.uint8)
+for s in range(base_n):
+    for j in range(rsdims):
+        cw = O.rs_encode(rng.integers(0, 256, 110, dtype=np.uint8))
+        ne = 0 if mode == "clean" else int(rng.choice([0, 0, 0, 0, 1, 2, 3, 5, 6]))
+        pos = rng.choice(120, ne, replace=False); cw[pos] ^= rng.integers(1, 256, ne, dtype=np.uint8)
+        p[s, :, j] = cw
+p = p.reshape(base_n, -1)
+ret_ref, out_ref = O.rs_check_batch(p, rsdims)
+d_p = torch.from_numpy(p).to(dev).repeat(nsf // base_n, 1).contiguous()
+d_out = torch.zeros((nsf, 110 * rsdims), dtype=torch.uint8, device=dev); d_ret = torch.zeros(nsf, dtype=torch.int32, device=dev)
+for _ in range(2): V.rs_batch_dev(d_p, d_out, d_ret, rsdims, nsf)
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(10): V.rs_batch_dev(d_p, d_out, d_ret, rsdims, nsf)
+b.record(); torch.cuda.synchronize(); ms = a.elapsed_time(b) / 10
+ok = bool(np.array_equal(d_ret[:base_n].cpu().numpy(), ret_ref)) and bool(np.array_equal(d_out[:base_n].cpu().numpy(), out_ref))
+print(json.dumps({"rsdims": rsdims, "nsf": nsf, "mode": mode, "ms": round(ms, 4), "Mcolumns_s": round(nsf * rsdims / ms / 1e3, 1),
+                  "GB_s": round(nsf * 230 * rsdims / ms / 1e6, 1), "parity_ok": ok}))

@@ -44,94 +44,127 @@ __device__ __forceinline__ uint32_t mod255(uint32_t x) { return (x * 0x1010102u)
 
 // Decode the codeword stored at col[k * RS_THREADS], k = 0..119 (LDS, transposed).
 // Returns root count, 0 when clean, -1 when uncorrectable; patches in place.
-__device__ int decode_rs(uint8_t* col, const uint8_t* __restrict__ ato, const uint8_t* __restrict__ iof) {
-    uint8_t s[16], lambda[16], b[16], root[16];
+// Every small polynomial array is indexed with compile-time constants only (loops fully
+// unrolled, data-dependent bounds turned into predicates): dynamically indexed register arrays
+// cost a v_cndmask chain per access on this target and made the error path ~8x slower.
+__device__ int decode_rs(uint8_t* col, const uint8_t* __restrict__ ato, const uint8_t* __restrict__ iof,
+                         const uint8_t* __restrict__ mulp) {
+    uint32_t s[NROOTS];
     const uint32_t d0 = col[0];
 #pragma unroll
-    for (int i = 0; i < 16; i++) { s[i] = (uint8_t)d0; root[i] = 0; }
+    for (int i = 0; i < NROOTS; i++) s[i] = d0;
     for (int j = 1; j < NCW; j++) {  // syndromes, Horner (rschecksf.cpp:212-219)
         const uint32_t d = col[j * RS_THREADS];
+        // s*alpha^i from a per-root product table (mulp[i][x] = x ? alpha_to[index_of[x]+i] : 0):
+        // one LDS byte per multiply-add instead of the log + antilog pair, same field arithmetic
+        s[0] ^= d;
 #pragma unroll
-        for (int i = 0; i < NROOTS; i++) s[i] = s[i] == 0 ? (uint8_t)d : (uint8_t)(d ^ ato[iof[s[i]] + i]);
+        for (int i = 1; i < NROOTS; i++) s[i] = d ^ mulp[i * 256 + s[i]];
     }
     uint32_t syn = 0;
 #pragma unroll
     for (int i = 0; i < NROOTS; i++) syn |= s[i];
     if (!syn) return 0;
 #pragma unroll
-    for (int i = 0; i <= NROOTS; i++) s[i] = iof[s[i]];
-#pragma unroll
-    for (int i = 0; i < 16; i++) { b[i] = 0xFF; lambda[i] = 0; }
-    b[0] = 0;
-    lambda[0] = 1;
+    for (int i = 0; i < NROOTS; i++) s[i] = iof[s[i]];  // index form (s[10] of the reference is never used)
 
+    // lambda / b: only entries 0..10 of the reference's 16-byte vectors are ever read
+    uint32_t lam[NROOTS + 1], b[NROOTS + 1];
+#pragma unroll
+    for (int i = 0; i <= NROOTS; i++) { lam[i] = 0; b[i] = NN; }
+    lam[0] = 1;
+    b[0] = 0;
     int el = 0;
+#pragma unroll
     for (int r = 1; r <= NROOTS; r++) {  // Berlekamp-Massey (rschecksf.cpp:240-284)
         uint32_t discr = 0;
+#pragma unroll
         for (int i = 0; i < r; i++)
-            if (lambda[i] != 0 && s[r - i - 1] != NN) discr ^= ato[iof[lambda[i]] + s[r - i - 1]];
+            if (lam[i] != 0 && s[r - i - 1] != NN) discr ^= ato[iof[lam[i]] + s[r - i - 1]];
         discr = iof[discr];
-        if (discr == NN) {
-            for (int i = 15; i > 0; i--) b[i] = b[i - 1];
-            b[0] = NN;
-        } else {
-            root[0] = lambda[0];
-            for (int i = 0; i < NROOTS; i++) {
-                root[i + 1] = lambda[i + 1];
-                if (b[i] != NN) root[i + 1] ^= ato[discr + b[i]];
-            }
-            if (2 * el <= r - 1) {
-                el = r - el;
-                for (int i = 0; i <= NROOTS; i++)
-                    b[i] = lambda[i] == 0 ? (uint8_t)NN : (uint8_t)mod255(iof[lambda[i]] - discr + NN);
-            } else {
-                for (int i = 15; i > 0; i--) b[i] = b[i - 1];
-                b[0] = NN;
-            }
-            for (int i = 0; i < 16; i++) lambda[i] = root[i];
+        const bool zero = discr == NN;
+        const bool grow = !zero && 2 * el <= r - 1;
+        uint32_t t[NROOTS + 1];
+        t[0] = lam[0];
+#pragma unroll
+        for (int i = 0; i < NROOTS; i++) {
+            t[i + 1] = lam[i + 1];
+            if (!zero && b[i] != NN) t[i + 1] ^= ato[discr + b[i]];
         }
+        if (grow) el = r - el;
+        // b <- inv(discr) * lambda (grow) or x * b (otherwise: _mm_slli_si128(b,1), b[0] = 255)
+#pragma unroll
+        for (int i = NROOTS; i >= 0; i--) {
+            const uint32_t scaled = lam[i] == 0 ? (uint32_t)NN : mod255(iof[lam[i]] - discr + NN);
+            const uint32_t shifted = i ? b[i - 1] : (uint32_t)NN;
+            b[i] = grow ? scaled : shifted;
+        }
+#pragma unroll
+        for (int i = 0; i <= NROOTS; i++) lam[i] = zero ? lam[i] : t[i];
     }
     int deg_lambda = 0;
-    for (int i = 0; i < NROOTS + 1; i++) {
-        lambda[i] = iof[lambda[i]];
-        if (lambda[i] != NN) deg_lambda = i;
+#pragma unroll
+    for (int i = 0; i <= NROOTS; i++) {
+        lam[i] = iof[lam[i]];
+        if (lam[i] != NN) deg_lambda = i;
     }
-    for (int i = 0; i < 16; i++) b[i] = lambda[i];
+    uint32_t c[NROOTS + 1];
+#pragma unroll
+    for (int i = 0; i <= NROOTS; i++) c[i] = lam[i];
+    uint32_t root[NROOTS];
+#pragma unroll
+    for (int k = 0; k < NROOTS; k++) root[k] = 0;
     int count = 0;
+    bool searching = true;
     for (int i = 1; i <= NN; i++) {  // Chien search (rschecksf.cpp:299-320)
-        uint32_t q = 1;
-        for (int j = deg_lambda; j > 0; j--)
-            if (b[j] != NN) {
-                b[j] = (uint8_t)mod255(b[j] + j);
-                q ^= ato[b[j]];
+        if (searching) {
+            uint32_t q = 1;
+#pragma unroll
+            for (int j = NROOTS; j > 0; j--)
+                if (c[j] != NN) {  // entries above deg_lambda are 255 by construction
+                    c[j] = mod255(c[j] + j);
+                    q ^= ato[c[j]];
+                }
+            if (q == 0) {
+#pragma unroll
+                for (int k = 0; k < NROOTS; k++)
+                    if (count == k) root[k] = (uint32_t)i;
+                if (++count == deg_lambda) searching = false;
             }
-        if (q != 0) continue;
-        root[count] = (uint8_t)i;
-        if (++count == deg_lambda) break;
+        }
+        if (!__any(searching)) break;
     }
     if (deg_lambda != count) return -1;
 
     const int deg_omega = deg_lambda - 1;
-    for (int i = 0; i <= deg_omega; i++) {  // omega (rschecksf.cpp:331-341)
+    uint32_t om[NROOTS];
+#pragma unroll
+    for (int i = 0; i < NROOTS; i++) {  // omega (rschecksf.cpp:331-341)
         uint32_t tmp = 0;
-        for (int j = i; j >= 0; j--)
-            if (s[i - j] != NN && lambda[j] != NN) tmp ^= ato[s[i - j] + lambda[j]];
-        b[i] = iof[tmp];
+#pragma unroll
+        for (int j = 0; j <= i; j++)
+            if (s[i - j] != NN && lam[j] != NN) tmp ^= ato[s[i - j] + lam[j]];
+        om[i] = i <= deg_omega ? (uint32_t)iof[tmp] : (uint32_t)NN;
     }
-    for (int j = count - 1; j >= 0; j--) {  // Forney (rschecksf.cpp:346-374)
+    const int top = (deg_lambda < NROOTS - 1 ? deg_lambda : NROOTS - 1) & ~1;
+#pragma unroll
+    for (int j = NROOTS - 1; j >= 0; j--) {  // Forney (rschecksf.cpp:346-374)
         const uint32_t rt = root[j];
-        if (rt < PADN + 1) continue;  // error in the virtual padding: skipped, still counted
-        uint32_t num1 = 0;
-        for (int i = deg_omega; i >= 0; i--)
-            if (b[i] != NN) num1 ^= ato[mod255(b[i] + i * rt)];
-        if (!num1) continue;
-        const uint32_t num2 = ato[NN - rt];
-        uint32_t den = 0;
-        const int top = deg_lambda < NROOTS - 1 ? deg_lambda : NROOTS - 1;
-        for (int i = top & ~1; i >= 0; i -= 2)
-            if (lambda[i + 1] != NN) den ^= ato[mod255(lambda[i + 1] + i * rt)];
-        const uint32_t tmp = (uint32_t)iof[num1] + iof[num2] + (NN - iof[den]);  // <= 763 < 768
-        col[(rt - 1 - PADN) * RS_THREADS] ^= ato[tmp];
+        if (j < count && rt >= PADN + 1) {  // roots in the virtual padding are skipped, still counted
+            uint32_t num1 = 0;
+#pragma unroll
+            for (int i = 0; i < NROOTS; i++)
+                if (i <= deg_omega && om[i] != NN) num1 ^= ato[mod255(om[i] + i * rt)];
+            if (num1) {
+                const uint32_t num2 = ato[NN - rt];
+                uint32_t den = 0;
+#pragma unroll
+                for (int i = 0; i < NROOTS; i += 2)
+                    if (i <= top && lam[i + 1] != NN) den ^= ato[mod255(lam[i + 1] + i * rt)];
+                const uint32_t tmp = (uint32_t)iof[num1] + iof[num2] + (NN - iof[den]);  // <= 763 < 768
+                col[(rt - 1 - PADN) * RS_THREADS] ^= ato[tmp];
+            }
+        }
     }
     return count;
 }
@@ -145,12 +178,14 @@ __global__ __launch_bounds__(RS_THREADS) void rs_kernel(const uint8_t* __restric
     __shared__ uint8_t cw[NCW * RS_THREADS];  // [row][lane]
     __shared__ uint8_t ato[768];
     __shared__ uint8_t iof[256];
+    __shared__ uint8_t mulp[NROOTS * 256];  // mulp[i][x] = x * alpha^i
     __shared__ int s_minfail[RS_THREADS];
     __shared__ int s_sum[RS_THREADS];
     __shared__ int s_fail[RS_THREADS];
     const int tid = threadIdx.x;
     for (int i = tid; i < 768; i += RS_THREADS) ato[i] = g_gf.ato[i];
     iof[tid] = g_gf.iof[tid];
+    for (int i = 0; i < NROOTS; i++) mulp[i * 256 + tid] = tid ? g_gf.ato[g_gf.iof[tid] + i] : 0;
     __syncthreads();
 
     const uint32_t spb = rsdims <= RS_THREADS ? RS_THREADS / rsdims : 1u;  // superframes per pass
@@ -176,7 +211,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_kernel(const uint8_t* __restric
             if (active) {
                 const uint8_t* src = p + (size_t)sf * in_sz + colidx;
                 for (int k = 0; k < NCW; k++) cw[k * RS_THREADS + tid] = src[(size_t)k * rsdims];
-                res = decode_rs(&cw[tid], ato, iof);
+                res = decode_rs(&cw[tid], ato, iof, mulp);
                 if (res < 0) atomicMin(&s_minfail[lsf], (int)colidx);
             }
             __syncthreads();

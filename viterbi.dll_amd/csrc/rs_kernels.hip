@@ -108,23 +108,25 @@ __device__ int decode_rs(uint8_t* col, const uint8_t* __restrict__ ato, const ui
         lam[i] = iof[lam[i]];
         if (lam[i] != NN) deg_lambda = i;
     }
+    // Chien search (rschecksf.cpp:299-320): the reference advances the logs b[j] += j and sums
+    // alpha_to[b[j]]; here the same terms lambda_j * alpha^(j*i) are kept in polynomial form and
+    // advanced with the product tables (one LDS byte per term, no mod-255 arithmetic).
     uint32_t c[NROOTS + 1];
 #pragma unroll
-    for (int i = 0; i <= NROOTS; i++) c[i] = lam[i];
+    for (int i = 0; i <= NROOTS; i++) c[i] = lam[i] == NN ? 0u : (uint32_t)ato[lam[i]];
     uint32_t root[NROOTS];
 #pragma unroll
     for (int k = 0; k < NROOTS; k++) root[k] = 0;
     int count = 0;
     bool searching = true;
-    for (int i = 1; i <= NN; i++) {  // Chien search (rschecksf.cpp:299-320)
+    for (int i = 1; i <= NN; i++) {
         if (searching) {
-            uint32_t q = 1;
+            uint32_t q = 1;  // lambda[0] is always 1
 #pragma unroll
-            for (int j = NROOTS; j > 0; j--)
-                if (c[j] != NN) {  // entries above deg_lambda are 255 by construction
-                    c[j] = mod255(c[j] + j);
-                    q ^= ato[c[j]];
-                }
+            for (int j = NROOTS; j > 0; j--) {
+                c[j] = mulp[j * 256 + c[j]];
+                q ^= c[j];
+            }
             if (q == 0) {
 #pragma unroll
                 for (int k = 0; k < NROOTS; k++)
@@ -178,14 +180,14 @@ __global__ __launch_bounds__(RS_THREADS) void rs_kernel(const uint8_t* __restric
     __shared__ uint8_t cw[NCW * RS_THREADS];  // [row][lane]
     __shared__ uint8_t ato[768];
     __shared__ uint8_t iof[256];
-    __shared__ uint8_t mulp[NROOTS * 256];  // mulp[i][x] = x * alpha^i
+    __shared__ uint8_t mulp[(NROOTS + 1) * 256];  // mulp[i][x] = x * alpha^i, i = 0..10
     __shared__ int s_minfail[RS_THREADS];
     __shared__ int s_sum[RS_THREADS];
     __shared__ int s_fail[RS_THREADS];
     const int tid = threadIdx.x;
     for (int i = tid; i < 768; i += RS_THREADS) ato[i] = g_gf.ato[i];
     iof[tid] = g_gf.iof[tid];
-    for (int i = 0; i < NROOTS; i++) mulp[i * 256 + tid] = tid ? g_gf.ato[g_gf.iof[tid] + i] : 0;
+    for (int i = 0; i <= NROOTS; i++) mulp[i * 256 + tid] = tid ? g_gf.ato[g_gf.iof[tid] + i] : 0;
     __syncthreads();
 
     const uint32_t spb = rsdims <= RS_THREADS ? RS_THREADS / rsdims : 1u;  // superframes per pass

@@ -33,7 +33,7 @@ POLYS = (109, 79, 83, 109)  # viterbi-benchmark.cpp:64
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def make_frames(nframes, framebits, seed, device):
+def make_frames(nframes, framebits, seed, device, ebn0_db=3.0, return_bits=False):
     """Reference-style synthetic input (viterbi-benchmark.cpp:293-311): random bits ->
     DAB mother code -> AWGN at Eb/N0 = 3 dB, sample = 127.5 + 32*N(+-gain,1), clip 0..255.
     Built on the GPU with a seeded torch generator; returns uint8 [nframes, 4*(framebits+6)]."""
@@ -54,12 +54,13 @@ def make_frames(nframes, framebits, seed, device):
         x = x ^ (x >> 2)
         x = x ^ (x >> 1)
         hard[:, :, j] = (x & 1).float()
-    esn0 = 3.0 + 10.0 * np.log10(1.0 / 4.0)
+    esn0 = ebn0_db + 10.0 * np.log10(1.0 / 4.0)
     gain = 1.0 / np.sqrt(0.5 / 10.0 ** (esn0 / 10.0))
     noise = torch.randn((nframes, T, 4), generator=g, device=device, dtype=torch.float32)
     v = 127.5 + 32.0 * ((hard * 2.0 - 1.0) * gain + noise)
     sym = v.to(torch.int32).clamp_(0, 255).to(torch.uint8)  # C truncation then clip
-    return sym.reshape(nframes, 4 * T).contiguous()
+    sym = sym.reshape(nframes, 4 * T).contiguous()
+    return (sym, bits[:, :framebits]) if return_bits else sym
 
 
 def cpu_baseline(O, sym_host, framebits, want_seconds=10.0):

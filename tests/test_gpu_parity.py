@@ -146,7 +146,7 @@ def test_u32_ingest_path(V, O, torch_cuda):
     assert np.array_equal(d_out.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("kernel", [0, 1, 2])
 def test_varlen_batch(V, O, torch_cuda, kernel):
     """BASELINE config 3 in small: framebits = 96*m, m in 3..72, descriptor table"""
     torch = torch_cuda
@@ -269,6 +269,24 @@ def test_dabplus_superframe_pipeline(V, O, torch_cuda):
     assert np.array_equal(d_work.cpu().numpy(), dec_ref)
     assert np.array_equal(d_ret.cpu().numpy(), ret_ref)
     assert np.array_equal(d_out.cpu().numpy(), out_ref)
+
+
+def test_ber_harness_matches_oracle(V, O, torch_cuda):
+    """viterbi-benchmark.cpp:293-329 analogue: at Eb/N0 = 3 dB the decoder is nearly error free, and
+    the GPU's error count equals the oracle's on the same frames (it is the same bits)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("vit_ber", os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "tools", "ber.py"))
+    ber = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ber)
+    r = ber.run(3.0, 400, 3072, seed=5)
+    assert r["ber"] < 2e-3
+    import bench
+    sym, bits = bench.make_frames(400, 3072, seed=5, device=torch_cuda.device("cuda:0"), return_bits=True)
+    ref = np.unpackbits(O.decode_batch(3072, sym.cpu().numpy(), nthreads=8), axis=1)
+    assert int((ref != bits.cpu().numpy()).sum()) == r["bit_errors"]
+    hard = ber.run(20.0, 50, 768, seed=1)  # essentially noise free
+    assert hard["bit_errors"] == 0
 
 
 # ---- BASELINE sizes through size-independent properties ----------------------------

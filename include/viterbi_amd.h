@@ -39,9 +39,11 @@ extern "C" {
 int deconvolve(unsigned int framebits, unsigned int *symbols, int unused,
                unsigned char *decodedBits);
 
-/* Replaces `initialize` (dllmain.cpp:156-160): re-reads the environment
- * (VITERBI_AMD_DEVICE), clears the fault state; cheap, idempotent; returns
- * non-zero (true). */
+/* Replaces `initialize` (dllmain.cpp:156-160): clears the fault state ("save
+ * mode") and makes sure the device probe has run; cheap, idempotent; returns
+ * non-zero (true).  The GPU is chosen once per process, at the first call into
+ * the library, from the environment variable VITERBI_AMD_DEVICE (index among the
+ * gfx950 devices, default 0) -- the analogue of the reference's viterbi.txt. */
 unsigned char initialize(void);
 
 /* Replaces `RScheckSuperframe` (rschecksf.cpp:65-93).  RS(120,110) over

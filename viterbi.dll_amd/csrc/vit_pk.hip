@@ -76,6 +76,9 @@ struct Lanes {
 #ifndef VIT_SWZ_ALL
 #define VIT_SWZ_ALL 0
 #endif
+#ifndef VIT_X01_DPP
+#define VIT_X01_DPP 0
+#endif
 template <int J>
 DEV void exchange(u32& A, u32& B, u32 N0, u32 N1, u32 lane) {
     if constexpr (J == 4) {
@@ -91,11 +94,19 @@ DEV void exchange(u32& A, u32& B, u32 N0, u32 N1, u32 lane) {
         A = __builtin_amdgcn_update_dpp(N0, N1, 0x114 /*row_shr:4*/, 0xF, 0xA, false);
         B = __builtin_amdgcn_update_dpp(N1, N0, 0x104 /*row_shl:4*/, 0xF, 0x5, false);
     } else {
-        // lane bits 0/1 cannot be masked by DPP bank masks: partner values through ds_swizzle
+        // lane bits 0/1 cannot be masked by DPP bank masks (and DPP needs the source lane active)
+        const bool hi = (lane >> J) & 1u;
+#if VIT_X01_DPP
+        // all-lane DPP moves + selects: 16 VALU cycles, but no LDS round trip in the dependency chain
+        constexpr int qp = J == 1 ? 0x4E /*quad_perm:[2,3,0,1]*/ : 0xB1 /*quad_perm:[1,0,3,2]*/;
+        const u32 p1 = __builtin_amdgcn_update_dpp(0u, N1, qp, 0xF, 0xF, true);
+        const u32 p0 = __builtin_amdgcn_update_dpp(0u, N0, qp, 0xF, 0xF, true);
+#else
+        // partner values through ds_swizzle (LDS crossbar, no VALU slot): 8 VALU cycles for the selects
         constexpr int pat = 0x1F | ((1 << J) << 10);  // BitMode: src lane = lane ^ 2^J within 32
         const u32 p1 = (u32)__builtin_amdgcn_ds_swizzle((int)N1, pat);
         const u32 p0 = (u32)__builtin_amdgcn_ds_swizzle((int)N0, pat);
-        const bool hi = (lane >> J) & 1u;
+#endif
         A = hi ? p1 : N0;
         B = hi ? N1 : p0;
     }
@@ -322,6 +333,9 @@ DEV void tb_run(u32& P, u32* scratch, int i_from, int i_to, bool on, u32 i_start
 // exactly the serial chainback.  ORs the decoded bits into img; returns P after step ts.
 DEV u32 traceback_part(const char* dec, u32* scratch, u32* img, u32 fstride, u32 lane, u32 ts, u32 te, u32 te_max,
                        u32 slot0, u32 P_top) {
+#ifdef VIT_DIAG_NO_TB
+    return P_top;  // timing-only diagnostic build: outputs are wrong
+#endif
     const u32 fi = lane >> 4, q = lane & 15u;
     const u32 span = te_max > ts ? te_max - ts : 0u;
     if (span == 0) return P_top;

@@ -168,6 +168,21 @@ def test_varlen_batch(V, O, torch_cuda, kernel):
     assert np.array_equal(d_out.cpu().numpy(), want)
 
 
+def test_random_lengths_and_batch_sizes(V, O, torch_cuda):
+    """sweep: every multiple of 8 around the segment / register-block boundaries plus random ones,
+    with batch sizes that leave ragged groups; uniform-length entry point, auto kernel selection"""
+    rng = np.random.default_rng(2025)
+    edges = [8, 16, 24, 104, 112, 120, 248, 256, 264, 272, 504, 512, 520, 760, 768, 776, 784, 792, 1544, 1552, 1560,
+             2336, 3128, 3136, 4096, 4104, 7840, 9208, 9216]
+    lengths = sorted(set(edges + (8 * rng.integers(1, 1153, 12)).tolist()))
+    for fb in lengths:
+        n = int(rng.integers(1, 10))
+        sym = _mixed_input(O, n, fb, seed=fb) if n > 1 else O.noisy_frames(1, fb, seed=fb)
+        want = O.decode_batch(fb, sym, nthreads=8)
+        got = _gpu_decode(V, torch_cuda, sym, fb, 0)
+        assert np.array_equal(got, want), "framebits=%d n=%d" % (fb, n)
+
+
 # ---- RS(120,110) -----------------------------------------------------------------
 
 def _rs_superframes(O, nsf, rsdims, seed, max_err=7):

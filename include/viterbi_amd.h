@@ -134,6 +134,12 @@ int vit_rs_batch_host(const uint8_t *h_p, uint8_t *h_out, int32_t *h_ret,
 int vit_dabplus_superframes_dev(const uint8_t *d_symbols_u8, uint8_t *d_work, uint8_t *d_rs_out,
                                 int32_t *d_ret, uint32_t RSDims, int64_t nsf, void *stream);
 
+/* Ingest stage for concurrent callers of deconvolve(): with a window > 0, calls arriving within
+ * `microseconds` of each other (from any threads) are decoded by ONE pack + ONE decode launch on a
+ * worker thread; each caller still blocks until its own frame is done.  0 (default) = every call on
+ * its own stream.  Returns the previous window. */
+int vit_set_batch_window_us(int microseconds);
+
 /* Kernel selection for experiments/tests: 0 = auto, 1 = wave-per-frame
  * reference kernel, 2 = packed 4-frames-per-wave kernel.  Returns the old
  * value.  Affects later vit_decode_* calls of the whole process. */

@@ -134,6 +134,32 @@ def test_deconvolve_is_thread_safe(V, O, torch_cuda):
     assert not errs
 
 
+def test_deconvolve_micro_batching(V, O, torch_cuda):
+    """ingest stage: concurrent callers share one launch; results and return codes unchanged"""
+    import threading
+    lens = [768, 768, 3072, 288, 1536, 768, 9216, 8]
+    syms = [O.uniform_symbols(O.sym_len(fb), seed=fb + i).astype(np.uint32) for i, fb in enumerate(lens)]
+    want = [O.deconvolve_u32(fb, s) for fb, s in zip(lens, syms)]
+    errs = []
+
+    def work(i):
+        for _ in range(15):
+            rc, got = V.deconvolve(lens[i], syms[i])
+            if rc != 0 or not np.array_equal(got, want[i]):
+                errs.append(i)
+
+    old = V.set_batch_window_us(200)
+    try:
+        th = [threading.Thread(target=work, args=(i,)) for i in range(len(lens))]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        rc, got = V.deconvolve(770, O.uniform_symbols(O.sym_len(770), seed=1).astype(np.uint32))  # not batched
+        assert rc == 0
+    finally:
+        V.set_batch_window_us(old)
+    assert not errs
+
+
 def test_u32_ingest_path(V, O, torch_cuda):
     torch = torch_cuda
     framebits, n = 768, 50

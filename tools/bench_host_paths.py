@@ -20,3 +20,20 @@ t0 = time.perf_counter()
 for _ in range(3): V.decode_batch_host(syms, fb)
 dt = (time.perf_counter() - t0) / 3
 print(json.dumps({"path": "vit_decode_batch_host 65536 FIC frames (pageable host memory, H2D+kernel+D2H)", "ms": round(dt * 1e3, 2), "Mbit_s": round(nf * fb / dt / 1e6, 1), "GB_s_in": round(syms.nbytes / dt / 1e9, 2)}))
+
+# ---- concurrent callers of deconvolve(): per-call streams vs the micro-batching ingest stage ----
+import threading
+def run_threads(nthreads, calls):
+    syms = [O.noisy_frames(1, fb, seed=10 + i)[0].astype(np.uint32) for i in range(nthreads)]
+    outs = [np.zeros(fb // 8, np.uint8) for _ in range(nthreads)]
+    def work(i):
+        for _ in range(calls):
+            V.deconvolve(fb, syms[i], 0, outs[i])
+    th = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
+    t0 = time.perf_counter(); [t.start() for t in th]; [t.join() for t in th]
+    return nthreads * calls / (time.perf_counter() - t0)
+for nt in (1, 8, 32):
+    V.set_batch_window_us(0); a = run_threads(nt, 300)
+    V.set_batch_window_us(50); b = run_threads(nt, 300)
+    V.set_batch_window_us(0)
+    print(json.dumps({"path": "deconvolve() from %d threads" % nt, "calls_per_s_unbatched": round(a), "calls_per_s_window_50us": round(b)}))

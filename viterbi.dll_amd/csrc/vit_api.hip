@@ -9,11 +9,15 @@
 // rschecksf.cpp:65-93, dllmain.cpp:156-160, setupdll.cpp:195-270 (dispatcher),
 // exc_handler.cpp:150-249 (fault -> save mode).
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
+#include <vector>
 
 #include "vit_internal.h"
 
@@ -155,6 +159,113 @@ int hip_device_ready() {
     return VIT_OK;
 }
 
+
+// ---- ingest stage: micro-batching of concurrent deconvolve() callers -------------
+// Off by default (window 0): every call then runs on its own thread's stream.  With a window of
+// w microseconds, callers park their request in a queue; one worker thread collects what arrives
+// within w us of the first request (or up to MAX_BATCH), stages all symbol buffers in pinned
+// memory, and runs ONE u32->u8 pack + ONE variable-length decode for the batch.
+struct BatchReq {
+    uint32_t framebits;
+    const unsigned int* symbols;
+    unsigned char* out;
+    int rc;
+    bool done;
+};
+struct Batcher {
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::vector<BatchReq*> q;
+    std::atomic<int> window_us{0};
+    bool started = false;
+    static constexpr size_t MAX_BATCH = 256;
+    std::vector<vit_frame_desc> h_desc;
+    void* d_desc = nullptr; size_t ddesc_cap = 0;
+
+    int process(std::vector<BatchReq*>& b) {
+        int rc = ctx_prepare();  // the worker thread has its own stream and buffers
+        if (rc != VIT_OK) return rc;
+        size_t nsym = 0, nout = 0;
+        uint32_t maxfb = 0;
+        h_desc.resize(b.size());
+        for (size_t i = 0; i < b.size(); i++) {
+            const uint32_t fb = b[i]->framebits;
+            h_desc[i].sym_offset = nsym;  // one byte per symbol after narrowing; multiple of 4
+            h_desc[i].out_offset = nout;
+            h_desc[i].framebits = fb;
+            h_desc[i].reserved = 0;
+            nsym += 4u * ((size_t)fb + VIT_TAIL);
+            nout += (fb + 7u) >> 3;
+            maxfb = fb > maxfb ? fb : maxfb;
+        }
+        const size_t desc_bytes = b.size() * sizeof(vit_frame_desc);
+        const size_t out_pad = (nout + 15u) & ~(size_t)15u;
+        if ((rc = grow_pin(nsym * 4 + out_pad + desc_bytes + 64)) != VIT_OK) return rc;
+        if ((rc = grow_dev(&t_ctx.d_in, &t_ctx.din_cap, nsym * 4)) != VIT_OK) return rc;
+        if ((rc = grow_dev(&t_ctx.d_sym8, &t_ctx.d8_cap, nsym)) != VIT_OK) return rc;
+        if ((rc = grow_dev(&t_ctx.d_out, &t_ctx.dout_cap, nout)) != VIT_OK) return rc;
+        if ((rc = grow_dev(&d_desc, &ddesc_cap, desc_bytes)) != VIT_OK) return rc;
+        unsigned char* pin = (unsigned char*)t_ctx.h_pin;
+        unsigned char* h_out = pin + nsym * 4;
+        unsigned char* h_d = h_out + out_pad;
+        size_t off = 0;
+        for (BatchReq* r : b) {
+            const size_t n = 4u * ((size_t)r->framebits + VIT_TAIL);
+            memcpy(pin + off * 4, r->symbols, n * 4);
+            off += n;
+        }
+        memcpy(h_d, h_desc.data(), desc_bytes);
+        hipStream_t s = t_ctx.stream;
+        HIPCHK(hipMemcpyAsync(t_ctx.d_in, pin, nsym * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(d_desc, h_d, desc_bytes, hipMemcpyHostToDevice, s));
+        hipError_t e = vit_launch_pack((const uint32_t*)t_ctx.d_in, (uint8_t*)t_ctx.d_sym8, (int64_t)nsym, s);
+        if (e != hipSuccess) { set_err("pack launch failed: %s", hipGetErrorString(e)); return VIT_ERR_HIP; }
+        // mixed parities of framebits/8 are fine for the packed kernel; odd framebits go one by one below
+        rc = launch_decode((const uint8_t*)t_ctx.d_sym8, (uint8_t*)t_ctx.d_out, (const vit_frame_desc*)d_desc, 0, maxfb,
+                           (int64_t)b.size(), s);
+        if (rc != VIT_OK) return rc;
+        HIPCHK(hipMemcpyAsync(h_out, t_ctx.d_out, nout, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        for (size_t i = 0; i < b.size(); i++)
+            memcpy(b[i]->out, h_out + h_desc[i].out_offset, (b[i]->framebits + 7u) >> 3);
+        return VIT_OK;
+    }
+
+    void run() {
+        std::vector<BatchReq*> batch;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return !q.empty(); });
+                const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us.load());
+                while (q.size() < MAX_BATCH && cv_work.wait_until(lk, deadline) != std::cv_status::timeout) {}
+                batch.swap(q);
+            }
+            const int rc = process(batch);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                for (BatchReq* r : batch) { r->rc = rc; r->done = true; }
+            }
+            cv_done.notify_all();
+            batch.clear();
+        }
+    }
+
+    int submit(uint32_t framebits, const unsigned int* symbols, unsigned char* out) {
+        BatchReq r{framebits, symbols, out, VIT_ERR_HIP, false};
+        std::unique_lock<std::mutex> lk(mu);
+        if (!started) {
+            started = true;
+            std::thread([this] { run(); }).detach();  // lives until the process ends
+        }
+        q.push_back(&r);
+        cv_work.notify_one();
+        cv_done.wait(lk, [&] { return r.done; });
+        return r.rc;
+    }
+};
+Batcher* g_batcher = new Batcher();  // intentionally never destroyed (worker may outlive static dtors)
+
 }  // namespace
 
 extern "C" {
@@ -164,6 +275,12 @@ const char* vit_last_error(void) { return t_err; }
 int vit_device_count(void) {
     ensure_init();
     return g_ndev;
+}
+
+int vit_set_batch_window_us(int microseconds) {
+    if (microseconds < 0) microseconds = 0;
+    if (microseconds > 100000) microseconds = 100000;
+    return g_batcher->window_us.exchange(microseconds);
 }
 
 int vit_set_kernel(int which) {
@@ -274,6 +391,14 @@ int deconvolve(unsigned int framebits, unsigned int* symbols, int unused, unsign
     if (!symbols || !decodedBits || !valid_framebits(framebits)) {
         set_err("deconvolve: bad arguments (framebits=%u)", framebits);
         return 1;
+    }
+    if (g_batcher->window_us.load() > 0 && (framebits % 8u) == 0) {
+        if (hip_device_ready() != VIT_OK) return 1;
+        if (g_batcher->submit(framebits, symbols, decodedBits) != VIT_OK) {
+            g_fault.store(1);
+            return 1;
+        }
+        return 0;
     }
     if (ctx_prepare() != VIT_OK) return 1;
     const size_t nsym = 4u * ((size_t)framebits + VIT_TAIL);

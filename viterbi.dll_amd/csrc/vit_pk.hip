@@ -1,5 +1,5 @@
 // vit_pk.hip -- packed K=7 r=1/4 Viterbi decoder for gfx950: FOUR frames per
-// wavefront, no cross-lane traffic through LDS in the add-compare-select loop.
+// wavefront, no cross-lane traffic through LDS memory in the add-compare-select loop.
 //
 // Layout.  A wave owns frames F(p,h), p = lane>>5 ("pair"), h = 16-bit half of a
 // VGPR.  Within a pair, the 64 path metrics of a frame live in two registers x 32
@@ -8,30 +8,41 @@
 // of its predecessors (i, i+32) from its own lane, and both survivors
 // (2i, 2i+1) stay in the lane.  After each step ONE register bit and ONE lane
 // bit swap roles (lane bit 4,3,2,1,0,4,... = 4 - t mod 5): v_permlane16_swap for
-// bit 4, masked DPP moves for bits 3..0.  The state <-> lane map rotates with
-// period 5, so the step body is unrolled 5-periodically (16 steps x 5 variants).
+// bit 4, masked DPP moves for bits 3/2, ds_swizzle + select for bits 1/0.  The
+// state <-> lane map rotates with period 5, so the step body is unrolled
+// 5-periodically (16 steps x 5 variants).
 //
 // Arithmetic.  Metrics are u16 lanes of v_pk_* instructions holding m + 0xFF00,
 // so `v_pk_add_u16 clamp` IS paddusb (saturation at 255).  The renormalisation
 // (`psubusb 63` when state 0 > 150, every second step) is `v_pk_sub_u16 clamp`
 // against 0xFF00 + {0,63}, which lands in a 0-based representation; the branch
 // metric table of the following (even) step carries the +0xFF00 back.  Decisions
-// are the sign bits of m0-m1 / m2-m3, shifted into two per-lane history registers
-// and stored to LDS every 16 steps (8 B/lane).
+// are the sign bits of m0-m1 / m2-m3, shifted into two per-lane history registers,
+// one 32-bit word pair (8 B/lane) per 16 steps.
 //
-// Branch metrics.  Only 8 distinct (b0,b1,b2) mask triples exist, so a 16-step
-// pre-pass (lane = frame x step) computes the 8 pavgb-tree metrics with byte-wide
-// v_lerp_u8 and writes a (M, 63-M) table to LDS; an ACS lane reads its 8 bytes.
+// Branch metrics.  Only 8 distinct (b0,b1,b2) mask triples exist, so a 32-step
+// pre-pass (lane = pair x step) computes the 8 pavgb-tree metrics of both frames of
+// its pair with byte-wide v_perm_b32 / v_lerp_u8 and writes a table of M to LDS; an
+// ACS lane reads its 4 bytes per step and forms 63-M with one v_sub.
 //
-// Decision storage.  LDS (160 KB/CU) is what limits resident waves, so only the
-// SECOND half of a frame's decision history is written to LDS; the first half stays
-// in VGPRs (two 32-dword register arrays indexed with s_set_gpr_idx) and is dumped
-// into the same LDS region after the second half has been traced back.
+// Decision storage.  LDS (160 KB/CU) is what limits resident waves.  Per segment of
+// 49 blocks (784 steps) the first 32 blocks of history stay in VGPRs (two 32-dword
+// register arrays indexed with s_set_gpr_idx), 16 go to LDS and the last one to the
+// start of the then-dead metric table: 10 KB of LDS per wave, 16 waves per CU.
+// Longer frames run in segments: a forward pass without history checkpoints the
+// metrics at segment boundaries, then the segments are recomputed with history and
+// traced back last to first.
 //
-// Traceback.  Two parts (second half, then first half), each blocked and speculative: lane = (frame, block of BL steps); every
-// block is traced from state 0, then re-traced from the state its successor block
-// ended in until nothing changes.  The last block really starts in state 0
-// (tail-terminated), so the fixed point is exactly the serial chainback.
+// Traceback.  Per segment three parts (LDS tail, then the register blocks 16 at a
+// time through the same LDS region), each blocked and speculative: lane = (frame,
+// block of BL steps); a block is traced from state 0 after a 30-step warm-up (or
+// from the true position when that reaches the frame end), checked against the
+// block above and re-traced until nothing changes.  The last block really starts
+// in state 0 (tail-terminated), so the fixed point is exactly the serial chainback.
+//
+// Instruction costs that shaped this (profiles/r01_valu_issue_rates_ubench.txt): v_pk_*,
+// VOP3 three-operand, DPP, SDWA, v_cmp = 4 cycles per wave; plain VOP2 = 2;
+// v_permlane*_swap = 8; v_cndmask_b32 via VCC ~22; SALU 1 instr/cycle/CU.
 //
 // Replaces, from scratch: decon_avx2 / Butterfly256 (deconvolve.cpp:334-387,
 // 514-526), Load8Syms256 (:219-228), Renormalize256 (:407-412), ChainBack

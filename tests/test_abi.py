@@ -56,3 +56,20 @@ def test_no_device_fails_loudly_without_cpu_fallback(V):
         V.decode_batch_host(np.zeros((1, 4 * 774), np.uint8), 768)
     # framebits == 0 is a successful no-op like the reference's C path
     assert V.lib().deconvolve(0, None, 0, None) == 0
+
+
+def test_call_log_env(tmp_path):
+    """VITERBI_AMD_LOG=<file>: one line per exported call (analogue of VIT_WRITE_LOGFILE,
+    deconvolve.cpp:568-649).  Runs in a child process because the variable is read at load time."""
+    import sys
+    log = tmp_path / "vit.log"
+    code = ("import sys; sys.path.insert(0, %r); import _vitpkg, numpy as np; V = _vitpkg.load_package();"
+            "V.deconvolve(768, np.zeros(4*774, np.uint32)); V.lib().deconvolve(0, None, 0, None);"
+            "V.RScheckSuperframe(np.zeros(480, np.uint8), 0, 4)" % ROOT)
+    env = dict(os.environ, VITERBI_AMD_LOG=str(log))
+    subprocess.check_call([sys.executable, "-c", code], env=env)
+    lines = log.read_text().strip().splitlines()
+    assert len(lines) == 3
+    assert "deconvolve" in lines[0] and "size: 768" in lines[0] and "ret:" in lines[0]
+    assert "size: 0" in lines[1] and lines[1].rstrip().endswith("ret: 0")
+    assert "RScheckSuperframe" in lines[2] and "size: 4" in lines[2]

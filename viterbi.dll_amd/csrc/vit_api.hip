@@ -32,6 +32,38 @@ void set_err(const char* fmt, ...) {
     if (getenv("VITERBI_AMD_VERBOSE")) fprintf(stderr, "[libviterbi] %s\n", t_err);
 }
 
+// ---- opt-in call log, the analogue of the reference's VIT_WRITE_LOGFILE build -------------------
+// (deconvolve.cpp:568-649, rschecksf.cpp:94-186): VITERBI_AMD_LOG=<path> appends one line per
+// exported call: sequence number, wall-clock time, thread id, call, size, duration, return value.
+struct CallLog {
+    FILE* f = nullptr;
+    std::mutex mu;
+    std::atomic<unsigned> seq{0};
+    CallLog() {
+        if (const char* p = getenv("VITERBI_AMD_LOG")) f = fopen(p, "a");
+    }
+    void line(const char* what, unsigned size, double us, int rc) {
+        if (!f) return;
+        const auto now = std::chrono::system_clock::now().time_since_epoch();
+        const long long usec = std::chrono::duration_cast<std::chrono::microseconds>(now).count();
+        std::lock_guard<std::mutex> lk(mu);
+        fprintf(f, "%6u  %lld.%06lld  TID: %zu  %s  size: %u  dur: %.1f us  ret: %d\n", seq++, usec / 1000000,
+                usec % 1000000, std::hash<std::thread::id>()(std::this_thread::get_id()) % 100000, what, size, us, rc);
+        fflush(f);
+    }
+};
+CallLog* g_log = new CallLog();  // never destroyed: calls may come from other threads during exit
+struct ScopedCall {
+    const char* what; unsigned size; int* rc; std::chrono::steady_clock::time_point t0;
+    ScopedCall(const char* w, unsigned s, int* r) : what(w), size(s), rc(r) {
+        if (g_log->f) t0 = std::chrono::steady_clock::now();
+    }
+    ~ScopedCall() {
+        if (g_log->f)
+            g_log->line(what, size, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), *rc);
+    }
+};
+
 // ---- process-wide state (written at init only, like deconJumpTarget) -------
 std::once_flag g_once;
 int g_ndev = 0;           // usable gfx950 devices
@@ -384,8 +416,15 @@ int vit_decode_batch_host(const uint8_t* h_symbols_u8, uint8_t* h_decoded, uint3
     return VIT_OK;
 }
 
+static int deconvolve_impl(unsigned int framebits, unsigned int* symbols, unsigned char* decodedBits);
 int deconvolve(unsigned int framebits, unsigned int* symbols, int unused, unsigned char* decodedBits) {
     (void)unused;  // never read by the reference either (deconvolve.cpp:447-526)
+    int rc = 1;
+    ScopedCall log("deconvolve", framebits, &rc);
+    rc = deconvolve_impl(framebits, symbols, decodedBits);
+    return rc;
+}
+static int deconvolve_impl(unsigned int framebits, unsigned int* symbols, unsigned char* decodedBits) {
     if (framebits == 0) return 0;  // C path: loop count 0, no memory touched
     if (g_fault.load()) return 1;  // save mode until initialize() (exc_handler.cpp:214,243)
     if (!symbols || !decodedBits || !valid_framebits(framebits)) {
@@ -492,8 +531,15 @@ int vit_rs_batch_host(const uint8_t* h_p, uint8_t* h_out, int32_t* h_ret, uint32
     return VIT_OK;
 }
 
+static int rscheck_impl(unsigned char* p, unsigned int RSDims, unsigned char* outVector);
 int RScheckSuperframe(unsigned char* p, int startIx, unsigned int RSDims, unsigned char* outVector) {
     (void)startIx;  // rschecksf.cpp:69
+    int rc = -1;
+    ScopedCall log("RScheckSuperframe", RSDims, &rc);
+    rc = rscheck_impl(p, RSDims, outVector);
+    return rc;
+}
+static int rscheck_impl(unsigned char* p, unsigned int RSDims, unsigned char* outVector) {
     if (RSDims == 0) return 0;
     if (g_fault.load()) return -1;
     if (!p || !outVector) {

@@ -342,7 +342,15 @@ DEV void tb_run(u32& P, u32* scratch, int i_from, int i_to, bool on, u32 i_start
 // which merges with the true path with high probability.  Afterwards every speculative block is
 // checked against the block above it and re-traced until nothing changes, so the result is
 // exactly the serial chainback.  ORs the decoded bits into img; returns P after step ts.
-DEV u32 traceback_part(const char* dec, u32* scratch, u32* img, u32 fstride, u32 lane, u32 ts, u32 te, u32 te_max,
+#ifndef VIT_TB_INLINE
+#define VIT_TB_INLINE 1
+#endif
+#if VIT_TB_INLINE
+DEV
+#else
+__device__ __attribute__((noinline))
+#endif
+u32 traceback_part(const char* dec, u32* scratch, u32* img, u32 fstride, u32 lane, u32 ts, u32 te, u32 te_max,
                        u32 slot0, u32 P_top) {
 #ifdef VIT_DIAG_NO_TB
     return P_top;  // timing-only diagnostic build: outputs are wrong
@@ -401,7 +409,7 @@ DEV u32 traceback_part(const char* dec, u32* scratch, u32* img, u32 fstride, u32
 
 // MULTI = false: every frame fits one segment (the FIC fast path; the phase loop folds away).
 #ifndef VIT_MULTI_WAVES
-#define VIT_MULTI_WAVES 2  /* 190 VGPRs without spills; measured faster than 3 or 4 with spills */
+#define VIT_MULTI_WAVES 3  /* 132 VGPRs, no spills */
 #endif
 template <bool MULTI>
 __global__ __launch_bounds__(64, MULTI ? VIT_MULTI_WAVES : 4) void vit_pk_kernel(const uint8_t* __restrict__ sym, uint8_t* __restrict__ out,
@@ -470,13 +478,13 @@ __global__ __launch_bounds__(64, MULTI ? VIT_MULTI_WAVES : 4) void vit_pk_kernel
     }
     u32 A = l5 == 0 ? 0u : 0x003F003Fu, B = 0x003F003Fu;  // const.asm:19-25 (0-based, step 0 is even)
     u32 acc0 = 0, acc1 = 0;
-    v32u r0, r1;          // register-resident decisions of the current segment's blocks [0,R)
     u32 P_next = P_ZERO;  // per frame: traceback position at the start of the segment above
 
     // Phases: forward over segments 0..nseg-1 (history only in the last one), then the earlier
     // segments again, last to first, recomputed from their checkpoints with history.
     const u32 nphase = 2u * nseg - 1u;
     auto phase = [&](const u32 ph) {
+        v32u r0, r1;  // register-resident decisions of this segment's blocks [0,R); dead at the end of the phase
         const bool fwd = ph < nseg;
         const u32 seg = fwd ? ph : 2u * nseg - 2u - ph;
         const bool hist = !fwd || seg + 1u == nseg;

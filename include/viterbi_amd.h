@@ -110,6 +110,11 @@ int vit_decode_batch_dev_u32(const uint32_t *d_symbols_u32, uint8_t *d_decoded,
 int vit_decode_varlen_dev(const uint8_t *d_symbols_u8, uint8_t *d_decoded,
                           const vit_frame_desc *d_desc, int64_t nframes,
                           uint32_t max_framebits, void *stream);
+/* Host helper: reorder a HOST array of descriptors by framebits (longest first, stable) before
+ * uploading it.  A wavefront decodes four consecutive descriptors and runs as long as the longest
+ * of them, so a length-sorted table is what a mixed batch wants (BASELINE config 3: +40 %);
+ * every descriptor carries its own offsets, so the order does not change any output byte. */
+void vit_sort_descs(vit_frame_desc *h_desc, int64_t nframes);
 /* u32 -> u8 narrowing of nsym symbols on the device (ingest stage). */
 int vit_pack_symbols_dev(const uint32_t *d_symbols_u32, uint8_t *d_symbols_u8,
                          int64_t nsym, void *stream);

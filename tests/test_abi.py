@@ -41,6 +41,15 @@ def test_frame_desc_layout(V):
     assert d["out_offset"].tolist() == [0, 96, 132] and ob == 133
 
 
+def test_sort_descs(V):
+    d, _, _ = V.make_descs([768, 288, 3072, 768, 8, 3072])
+    before = {(int(x["framebits"]), int(x["sym_offset"]), int(x["out_offset"])) for x in d}
+    V.sort_descs(d)
+    assert d["framebits"].tolist() == [3072, 3072, 768, 768, 288, 8]
+    assert {(int(x["framebits"]), int(x["sym_offset"]), int(x["out_offset"])) for x in d} == before
+    assert d["sym_offset"][0] < d["sym_offset"][1] and d["sym_offset"][2] < d["sym_offset"][3]  # stable
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
 def test_no_device_fails_loudly_without_cpu_fallback(V):
     assert V.device_count() == 0

@@ -182,6 +182,8 @@ def test_varlen_batch(V, O, torch_cuda, kernel):
     sym = O.uniform_symbols(sym_bytes, seed=4)
     want = np.concatenate([O.decode_batch(fb, sym[int(d["sym_offset"]):int(d["sym_offset"]) + O.sym_len(fb)])[0]
                            for fb, d in zip(fbs, desc)])
+    if kernel == 2:
+        desc = V.sort_descs(desc.copy())  # the order of the table must not change any output byte
     old = V.set_kernel(kernel)
     try:
         d_sym = torch.from_numpy(sym).cuda()

@@ -50,9 +50,12 @@ for fb in (288, 768, 1536, 2304, 3072, 4096, 6912):
 rng = np.random.default_rng(3)
 n = 32768
 fbs = 96 * rng.integers(3, 73, n)
-for label, order in (("as drawn", np.arange(n)), ("sorted by length", np.argsort(fbs, kind="stable"))):
-    f = fbs[order]
+for label in ("as drawn", "vit_sort_descs"):
+    f = fbs
     desc, sym_bytes, out_bytes = V.make_descs(f.tolist())
+    if label == "vit_sort_descs":
+        V.sort_descs(desc)
+        f = desc["framebits"].astype(np.int64)
     sym = torch.randint(0, 256, (sym_bytes,), dtype=torch.uint8, device=dev)
     out = torch.zeros(out_bytes, dtype=torch.uint8, device=dev)
     d_desc = torch.from_numpy(desc.view(np.uint8)).to(dev)

@@ -21,7 +21,7 @@ TAIL = 6
 EXPORTS = [
     "deconvolve", "initialize", "RScheckSuperframe", "RSCheckSuperframe", "GetCPUCaps", "WakeUpYMM",
     "vit_last_error", "vit_device_count", "vit_set_kernel", "vit_set_batch_window_us", "vit_decode_batch_dev",
-    "vit_decode_batch_dev_u32", "vit_decode_varlen_dev", "vit_pack_symbols_dev",
+    "vit_decode_batch_dev_u32", "vit_decode_varlen_dev", "vit_pack_symbols_dev", "vit_sort_descs",
     "vit_decode_batch_host", "vit_rs_batch_dev", "vit_rs_batch_host", "vit_dabplus_superframes_dev",
 ]
 
@@ -72,6 +72,8 @@ def lib():
         L.vit_decode_batch_dev_u32.argtypes = [vp, vp, C.c_uint32, C.c_int64, vp]
         L.vit_decode_varlen_dev.argtypes = [vp, vp, vp, C.c_int64, C.c_uint32, vp]
         L.vit_pack_symbols_dev.argtypes = [vp, vp, C.c_int64, vp]
+        L.vit_sort_descs.argtypes = [vp, C.c_int64]
+        L.vit_sort_descs.restype = None
         L.vit_decode_batch_host.argtypes = [vp, vp, C.c_uint32, C.c_int64]
         L.vit_rs_batch_dev.argtypes = [vp, vp, vp, C.c_uint32, C.c_int64, vp]
         L.vit_rs_batch_host.argtypes = [vp, vp, vp, C.c_uint32, C.c_int64]
@@ -186,6 +188,13 @@ def decode_varlen_dev(d_symbols_u8, d_out, d_desc, nframes, max_framebits, strea
     _check(lib().vit_decode_varlen_dev(C.c_void_p(d_symbols_u8.data_ptr()), C.c_void_p(d_out.data_ptr()),
                                        C.c_void_p(d_desc.data_ptr()), nframes, max_framebits,
                                        _stream_ptr(stream)), "vit_decode_varlen_dev")
+
+
+def sort_descs(desc):
+    """in-place, longest first (host numpy array of DESC_DTYPE)"""
+    assert desc.dtype == DESC_DTYPE and desc.flags["C_CONTIGUOUS"]
+    lib().vit_sort_descs(_np(desc), desc.size)
+    return desc
 
 
 def pack_symbols_dev(d_symbols_u32, d_symbols_u8, nsym, stream=None):

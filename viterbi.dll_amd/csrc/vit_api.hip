@@ -8,6 +8,7 @@
 // Reference boundary being replaced: viterbi.def:4-8, deconvolve.cpp:551-554,
 // rschecksf.cpp:65-93, dllmain.cpp:156-160, setupdll.cpp:195-270 (dispatcher),
 // exc_handler.cpp:150-249 (fault -> save mode).
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -393,6 +394,12 @@ int vit_decode_varlen_dev(const uint8_t* d_symbols_u8, uint8_t* d_decoded, const
     }
     if (nframes == 0 || max_framebits == 0) return VIT_OK;
     return launch_decode(d_symbols_u8, d_decoded, d_desc, 0, max_framebits, nframes, (hipStream_t)stream);
+}
+
+void vit_sort_descs(vit_frame_desc* h_desc, int64_t nframes) {
+    if (!h_desc || nframes <= 1) return;
+    std::stable_sort(h_desc, h_desc + nframes,
+                     [](const vit_frame_desc& a, const vit_frame_desc& b) { return a.framebits > b.framebits; });
 }
 
 int vit_decode_batch_host(const uint8_t* h_symbols_u8, uint8_t* h_decoded, uint32_t framebits, int64_t nframes) {

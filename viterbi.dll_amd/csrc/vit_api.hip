@@ -106,6 +106,7 @@ struct ThreadCtx {
     void* d_sym8 = nullptr;  size_t d8_cap = 0;  // packed symbols
     void* d_out = nullptr;   size_t dout_cap = 0;
     void* d_ret = nullptr;   size_t dret_cap = 0;
+    hipEvent_t scratch_ev = nullptr;  // last use of d_sym8 by a *_dev call on a caller-owned stream
     bool ready = false;
     ~ThreadCtx() {
         if (!ready) return;
@@ -115,6 +116,7 @@ struct ThreadCtx {
         if (d_sym8) (void)hipFree(d_sym8);
         if (d_out) (void)hipFree(d_out);
         if (d_ret) (void)hipFree(d_ret);
+        if (scratch_ev) (void)hipEventDestroy(scratch_ev);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -378,10 +380,16 @@ int vit_decode_batch_dev_u32(const uint32_t* d_symbols_u32, uint8_t* d_decoded, 
     const size_t nsym = (size_t)nframes * 4u * (framebits + VIT_TAIL);
     rc = grow_dev(&t_ctx.d_sym8, &t_ctx.d8_cap, nsym);  // may synchronise the device (hipMalloc)
     if (rc != VIT_OK) return rc;
+    // the narrowed symbols live in this thread's scratch buffer: order its reuse across the caller's streams
+    if (!t_ctx.scratch_ev) HIPCHK(hipEventCreateWithFlags(&t_ctx.scratch_ev, hipEventDisableTiming));
+    else HIPCHK(hipStreamWaitEvent((hipStream_t)stream, t_ctx.scratch_ev, 0));
     hipError_t e = vit_launch_pack(d_symbols_u32, (uint8_t*)t_ctx.d_sym8, (int64_t)nsym, (hipStream_t)stream);
     if (e != hipSuccess) { set_err("pack launch failed: %s", hipGetErrorString(e)); return VIT_ERR_HIP; }
-    return launch_decode((const uint8_t*)t_ctx.d_sym8, d_decoded, nullptr, framebits, framebits, nframes,
-                         (hipStream_t)stream);
+    rc = launch_decode((const uint8_t*)t_ctx.d_sym8, d_decoded, nullptr, framebits, framebits, nframes,
+                       (hipStream_t)stream);
+    if (rc != VIT_OK) return rc;
+    HIPCHK(hipEventRecord(t_ctx.scratch_ev, (hipStream_t)stream));
+    return VIT_OK;
 }
 
 int vit_decode_varlen_dev(const uint8_t* d_symbols_u8, uint8_t* d_decoded, const vit_frame_desc* d_desc,

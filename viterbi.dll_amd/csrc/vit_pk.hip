@@ -47,6 +47,8 @@
 // Replaces, from scratch: decon_avx2 / Butterfly256 (deconvolve.cpp:334-387,
 // 514-526), Load8Syms256 (:219-228), Renormalize256 (:407-412), ChainBack
 // (:416-435), chainback.inc:18-41 and const.asm:19-63.
+#include <mutex>
+
 #include "vit_internal.h"
 
 namespace {
@@ -603,16 +605,16 @@ hipError_t vit_launch_pk(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_d
                          uint32_t max_framebits, int64_t nframes, hipStream_t stream) {
     if (nframes <= 0) return hipSuccess;
     if (!vit_pk_supported(max_framebits)) return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vit_pk_kernel<false>),
+    static std::once_flag attr_once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(vit_pk_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (attr_err == hipSuccess)
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(vit_pk_kernel<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(vit_pk_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    });
+    if (attr_err != hipSuccess) return attr_err;
     const long long groups = (nframes + 3) / 4;
     if (groups > 0x7FFFFFFFLL) return hipErrorInvalidValue;
     const PkLayout lay = pk_layout(max_framebits);

@@ -8,6 +8,8 @@
 // Replaces, from scratch: decon_avx2 / Butterfly256 (deconvolve.cpp:334-387,
 // 514-526), Renormalize256 (:407-412), ChainBack (:416-435) and the constant
 // block const.asm:19-63 (the masks are recomputed from the polynomials).
+#include <mutex>
+
 #include "vit_internal.h"
 
 namespace {
@@ -105,13 +107,13 @@ hipError_t vit_launch_wave(const uint8_t* d_sym, uint8_t* d_out, const vit_frame
                            hipStream_t stream) {
     if (nframes <= 0) return hipSuccess;
     const size_t lds = (size_t)(max_framebits + VIT_TAIL) * 8u;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vit_wave_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static std::once_flag attr_once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(vit_wave_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    });
+    if (attr_err != hipSuccess) return attr_err;
     const long long grid = nframes < (1 << 20) ? nframes : (1 << 20);
     hipLaunchKernelGGL(vit_wave_kernel, dim3((unsigned)grid), dim3(64), lds, stream, d_sym, d_out, d_desc,
                        framebits, (long long)nframes);

@@ -106,7 +106,10 @@ int vit_decode_batch_dev(const uint8_t *d_symbols_u8, uint8_t *d_decoded,
 int vit_decode_batch_dev_u32(const uint32_t *d_symbols_u32, uint8_t *d_decoded,
                              uint32_t framebits, int64_t nframes, void *stream);
 /* Variable-length batch; d_desc is a DEVICE array of nframes descriptors,
- * max_framebits the largest framebits in it (host-known). */
+ * max_framebits the largest framebits in it (host-known).  A descriptor whose
+ * framebits exceeds max_framebits is skipped (its output bytes stay untouched);
+ * if any framebits is not a multiple of 8 the whole batch must go through
+ * vit_set_kernel(1), the wave-per-frame kernel. */
 int vit_decode_varlen_dev(const uint8_t *d_symbols_u8, uint8_t *d_decoded,
                           const vit_frame_desc *d_desc, int64_t nframes,
                           uint32_t max_framebits, void *stream);

@@ -211,6 +211,29 @@ def test_random_lengths_and_batch_sizes(V, O, torch_cuda):
         assert np.array_equal(got, want), "framebits=%d n=%d" % (fb, n)
 
 
+def test_varlen_descriptor_longer_than_declared_is_skipped(V, O, torch_cuda):
+    torch = torch_cuda
+    fbs = [768, 1536, 768, 768, 288]
+    desc, sym_bytes, out_bytes = V.make_descs(fbs)
+    sym = O.uniform_symbols(sym_bytes, seed=8)
+    for kernel in (1, 2):
+        old = V.set_kernel(kernel)
+        try:
+            d_out = torch.full((out_bytes,), 0x5A, dtype=torch.uint8, device="cuda")
+            V.decode_varlen_dev(torch.from_numpy(sym).cuda(), d_out, torch.from_numpy(desc.view(np.uint8)).cuda(),
+                                len(fbs), 768)  # the 1536-bit frame exceeds the declared maximum
+            torch.cuda.synchronize()
+        finally:
+            V.set_kernel(old)
+        got = d_out.cpu().numpy()
+        for fb, d in zip(fbs, desc):
+            so, oo = int(d["sym_offset"]), int(d["out_offset"])
+            if fb > 768:
+                assert (got[oo:oo + fb // 8] == 0x5A).all()
+            else:
+                assert np.array_equal(got[oo:oo + fb // 8], O.decode_batch(fb, sym[so:so + O.sym_len(fb)])[0])
+
+
 # ---- RS(120,110) -----------------------------------------------------------------
 
 def _rs_superframes(O, nsf, rsdims, seed, max_err=7):

@@ -252,12 +252,14 @@ struct PkLayout {
     u32 cp_off;     // checkpoints (nseg - 1) x 512 B, 0 if none
     u32 img_off;    // output bit image
     u32 total;
+    u32 maxfb;      // the framebits this layout was sized for
 };
 __host__ __device__ inline PkLayout pk_layout(u32 maxfb) {
     const u32 nblk = (maxfb + VIT_TAIL + 15u) >> 4;
     const u32 nseg = (nblk + SEG_BLOCKS - 1u) / SEG_BLOCKS;
     const u32 nb = nblk < SEG_BLOCKS ? nblk : SEG_BLOCKS;
     PkLayout l;
+    l.maxfb = maxfb;
     l.dec_bytes = (nb - pk_reg_blocks(nb) - 1u) * DEC_BLOCK;
     const u32 scratch = 64u * 4u * pk_scratch_words(maxfb), img = 16u * pk_img_stride(maxfb);
     if (nseg == 1) {  // the image can live in the dead table region too
@@ -439,6 +441,9 @@ __global__ __launch_bounds__(64, MULTI ? VIT_MULTI_WAVES : 4) void vit_pk_kernel
                 fbits[k] = desc[f].framebits;
                 soff[k] = desc[f].sym_offset;
                 ooff[k] = desc[f].out_offset;
+                // a descriptor the launch was not sized for (longer than max_framebits, or not a
+                // multiple of 8) is skipped rather than allowed to run off the LDS layout
+                if (fbits[k] > lay.maxfb || (fbits[k] & 7u)) fbits[k] = 0;
             } else {
                 fbits[k] = framebits_uniform;
                 soff[k] = (size_t)f * 4u * (framebits_uniform + VIT_TAIL);

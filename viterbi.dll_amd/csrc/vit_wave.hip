@@ -25,7 +25,7 @@ __device__ __forceinline__ uint32_t avg4(uint32_t a, uint32_t b) {
 __global__ __launch_bounds__(64) void vit_wave_kernel(const uint8_t* __restrict__ sym,
                                                       uint8_t* __restrict__ out,
                                                       const vit_frame_desc* __restrict__ desc,
-                                                      uint32_t framebits_uniform,
+                                                      uint32_t framebits_uniform, uint32_t max_framebits,
                                                       long long nframes) {
     extern __shared__ unsigned long long dec[];  // one 64-bit decision word per step
     const uint32_t lane = threadIdx.x;
@@ -44,6 +44,7 @@ __global__ __launch_bounds__(64) void vit_wave_kernel(const uint8_t* __restrict_
             framebits = desc[f].framebits;
             sym_off = desc[f].sym_offset;
             out_off = desc[f].out_offset;
+            if (framebits > max_framebits) continue;  // the launch's LDS was not sized for it: skipped
         } else {
             sym_off = (size_t)f * 4u * (framebits + VIT_TAIL);
             out_off = (size_t)f * (framebits >> 3);
@@ -116,7 +117,7 @@ hipError_t vit_launch_wave(const uint8_t* d_sym, uint8_t* d_out, const vit_frame
     if (attr_err != hipSuccess) return attr_err;
     const long long grid = nframes < (1 << 20) ? nframes : (1 << 20);
     hipLaunchKernelGGL(vit_wave_kernel, dim3((unsigned)grid), dim3(64), lds, stream, d_sym, d_out, d_desc,
-                       framebits, (long long)nframes);
+                       framebits, max_framebits, (long long)nframes);
     return hipGetLastError();
 }
 

@@ -150,14 +150,19 @@ DEV void acs_step(u32& A, u32& B, u32& acc0, u32& acc1, u32 mt, u32 lane, const 
         // Renormalize256: state 0 (lane 0 of the pair, register N0) > 150 -> psubusb 63.
         // z = m + 0xFF00 per half.  z + 0x8069 has bit 15 set iff m >= 151; done as ONE 32-bit add:
         // the low half always carries out (0xFF00 + 0x8069 >= 2^16), so the high constant is 0x8068.
+        // The subtrahend is per frame, i.e. the same for every lane and both registers of a pair, so it
+        // commutes with the lane exchange: the broadcast and the exchange are issued together and
+        // the subtraction lands on the exchanged registers (one LDS latency instead of two in a row).
         const u32 z = (u32)__builtin_amdgcn_ds_swizzle((int)W(n0), 0);  // lane 0 of each 32-lane group
+        exchange<4 - RHO>(A, B, W(n0), W(n1), lane);
         const u32 w = z + 0x80688069u;
         const u32 t = (w >> 15) & 0x00010001u;
         const u32 K = t * 63u + C.hi;  // v_mad_u32_u24: 0xFF00 + {0,63} per half
-        n0 = __builtin_elementwise_sub_sat(n0, U(K));           // -> 0-based representation
-        n1 = __builtin_elementwise_sub_sat(n1, U(K));
+        A = W(__builtin_elementwise_sub_sat(U(A), U(K)));  // -> 0-based representation
+        B = W(__builtin_elementwise_sub_sat(U(B), U(K)));
+    } else {
+        exchange<4 - RHO>(A, B, W(n0), W(n1), lane);
     }
-    exchange<4 - RHO>(A, B, W(n0), W(n1), lane);
 }
 
 template <int V, int J, bool HIST>

@@ -195,3 +195,17 @@ def test_golden_fixtures(O):
         p = np.frombuffer(bytes.fromhex(case["p_hex"]), np.uint8)
         rc, out = O.rs_check_superframe(p, case["rsdims"], np.full(110 * case["rsdims"], 0xA5, np.uint8))
         assert rc == case["ret"] and out.tobytes().hex() == case["out_hex"]
+
+
+def test_packed_layout_emulation(O):
+    """CPU-only check of the packed kernel's index math (tools/emulate_pk.py): rotating lane<->state
+    map, table triples, decision-history layout and the traceback position formula, emulated lane by
+    lane in numpy, must reproduce the oracle."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "emulate_pk", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "emulate_pk.py"))
+    emu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(emu)
+    for fb in (40, 136):
+        sym = np.concatenate([O.noisy_frames(2, fb, seed=fb), O.uniform_symbols(2 * O.sym_len(fb), seed=fb + 1).reshape(2, -1)])
+        assert np.array_equal(emu.emulate(sym, fb), O.decode_batch(fb, sym))

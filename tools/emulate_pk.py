@@ -1,8 +1,11 @@
 """Lane-level numpy emulation of vit_pk.hip's data layout (debug/validation tool).
 
-Emulates one wave (4 frames): pre-pass table, packed ACS with the rotating
-lane<->state map, decision history layout and the blocked speculative traceback,
-and compares the decoded bytes with the oracle.  Run: python tools/emulate_pk.py
+Emulates one wave (4 frames): a pre-pass table of (M, 63-M) pairs (the kernel's first table
+format; today it stores M only and splits the pre-pass differently, same values), the packed ACS
+with the rotating lane<->state map, u16 biased arithmetic, renormalisation, the decision-history
+layout, and a serial traceback through that layout with the physical position formula
+l = ror5(state>>1, t mod 5).  Compares the decoded bytes with the oracle; also run by
+tests/test_oracle_kat.py::test_packed_layout_emulation.  Run: python tools/emulate_pk.py [framebits]
 """
 import os
 import sys

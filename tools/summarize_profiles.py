@@ -65,6 +65,12 @@ if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
                              "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a streaming read)"}, f, indent=1)
 if avg_ns:
     lines.append("kernel avg (rocprof) %.1f us vs bench HIP-event kernel_ms %.4f ms\n" % (avg_ns / 1e3, bench["roofline"]["kernel_ms"]))
+if "SQ_ACTIVE_INST_VALU" in tot and "GRBM_GUI_ACTIVE" in tot:
+    # MI355X_MICROARCH.md: SQ_ACTIVE_INST_* count quad-cycles per wave; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+    kernel_cycles = tot["GRBM_GUI_ACTIVE"] / 8.0
+    valu_busy = tot["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * kernel_cycles)
+    lines.append("kernel cycles %.4g (clock %.2f GHz); VALU busy = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * cycles) = %.1f %%\n"
+                 % (kernel_cycles, kernel_cycles / (avg_ns or 1) , 100.0 * valu_busy))
 if "SQ_WAVES" in tot:
     w = tot["SQ_WAVES"]
     lines.append("per wave: VALU %.0f  SALU %.0f  LDS %.0f  wave-cycles(quad) %.0f\n" % (

@@ -92,6 +92,9 @@ struct Lanes {
 #ifndef VIT_X01_DPP
 #define VIT_X01_DPP 0
 #endif
+#ifndef VIT_K3
+#define VIT_K3 0
+#endif
 template <int J>
 DEV void exchange(u32& A, u32& B, u32 N0, u32 N1, u32 lane) {
     if constexpr (J == 4) {
@@ -155,9 +158,19 @@ DEV void acs_step(u32& A, u32& B, u32& acc0, u32& acc1, u32 mt, u32 lane, const 
         // the subtraction lands on the exchanged registers (one LDS latency instead of two in a row).
         const u32 z = (u32)__builtin_amdgcn_ds_swizzle((int)W(n0), 0);  // lane 0 of each 32-lane group
         exchange<4 - RHO>(A, B, W(n0), W(n1), lane);
+#if VIT_K3
+        // three instructions: v_pk_add_u16 (bit 15 of each half := m >= 151), v_pk_ashrrev_i16 15, v_and_or_b32
+        u32 K;
+        asm("v_pk_add_u16 %0, %1, %2\n\t"
+            "v_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]\n\t"
+            "v_and_or_b32 %0, %0, %3, %4"
+            : "=&v"(K)
+            : "v"(z), "s"(0x80698069u), "s"(0x003F003Fu), "v"(C.hi));
+#else
         const u32 w = z + 0x80688069u;
         const u32 t = (w >> 15) & 0x00010001u;
         const u32 K = t * 63u + C.hi;  // v_mad_u32_u24: 0xFF00 + {0,63} per half
+#endif
         A = W(__builtin_elementwise_sub_sat(U(A), U(K)));  // -> 0-based representation
         B = W(__builtin_elementwise_sub_sat(U(B), U(K)));
     } else {

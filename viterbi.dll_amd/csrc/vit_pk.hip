@@ -133,8 +133,9 @@ struct Consts {
 };
 
 // One trellis step for 4 frames (deconvolve.cpp:352-374 in packed u16 form).
-template <int RHO, bool ODD, bool HIST>
+template <int RHO, int J, bool HIST>
 DEV void acs_step(u32& A, u32& B, u32& acc0, u32& acc1, u32 mt, u32 lane, const Consts& C) {
+    constexpr bool ODD = (J & 1) != 0;
     // 63 - M per half as ONE 32-bit subtract.  Odd steps: M <= 63, no borrow.  Even steps carry the
     // +0xFF00 bias: (0xFE3F - M') mod 2^16 per half; the low half always borrows, hence 0xFE40 on top.
     const us2 a = U(A), b = U(B), M = U(mt), MM = U((ODD ? 0x003F003Fu : 0xFE40FE3Fu) - mt);
@@ -144,10 +145,20 @@ DEV void acs_step(u32& A, u32& B, u32& acc0, u32& acc1, u32 mt, u32 lane, const 
     // sign(m0-m1) = 1  <=>  m0 < m1  <=>  decision bit 0 (tie -> decision 1)
     if constexpr (HIST) {
         const us2 x01 = m0 - m1, x23 = m2 - m3;
-        // history: plain 32-bit shift (2 cycles) + v_bfi (4); the bfi also discards the bit that the
-        // 32-bit shift carries from the upper half into bit 15
-        acc0 = bfi(0x80008000u, W(x01), acc0 >> 1);
-        acc1 = bfi(0x80008000u, W(x23), acc1 >> 1);
+        // history: |m0 - m1| <= 255, so bits 9..15 of each half of the difference are seven copies
+        // of its sign, and one v_bfi can drop the decision at any of those positions.  Step j of
+        // the block ends up at bit j of its half with only TWO 32-bit shifts per 16 steps:
+        //   steps 0,1 -> bits 14,15 | >>7 | steps 2..8 -> bits 9..15 | >>7 | steps 9..15 -> bits 9..15
+        // (what a shift carries from the upper half into bits 9..15 is overwritten by the seven
+        // inserts that follow it; the stale bits of the previous block are shifted out).
+        constexpr int pos = J < 2 ? 14 + J : J < 9 ? 7 + J : J;
+        constexpr u32 mask = 0x00010001u << pos;
+        if constexpr (J == 2 || J == 9) {
+            acc0 >>= 7;
+            acc1 >>= 7;
+        }
+        acc0 = bfi(mask, W(x01), acc0);
+        acc1 = bfi(mask, W(x23), acc1);
     }
     if constexpr (ODD) {
         // Renormalize256: state 0 (lane 0 of the pair, register N0) > 150 -> psubusb 63.
@@ -184,7 +195,7 @@ struct Steps {
                         const Consts& C) {
         constexpr int RHO = (V + J) % 5;
         const u32 mt = *reinterpret_cast<const u32*>(tab + L.toff[RHO] + J * 64);
-        acs_step<RHO, (J & 1) != 0, HIST>(A, B, acc0, acc1, mt, lane, C);
+        acs_step<RHO, J, HIST>(A, B, acc0, acc1, mt, lane, C);
         Steps<V, J + 1, HIST>::run(A, B, acc0, acc1, tab, L, lane, C);
     }
 };

@@ -626,14 +626,199 @@ __global__ __launch_bounds__(64, MULTI ? VIT_MULTI_WAVES : 4) void vit_pk_kernel
     }
 }
 
+
+// ---- frames longer than one segment: decisions beyond the last 17 blocks go through HBM ---------
+// (replaces the checkpoint + recompute scheme: one forward pass with history; HBM has >90 % headroom
+// on this VALU-bound path, so 8 B/step of spill each way is cheaper than 0.7 extra ACS passes.)
+// Blocks [0, G) of a wave's frames are written to its slice of `spill` (512 B per block, coalesced),
+// the last <= 17 blocks stay in LDS exactly as in the single-segment kernel.  The traceback walks
+// down from the LDS tail, then reloads 16 spilled blocks at a time into the same LDS region.
+// Workgroups are persistent: each takes the next group of 4 frames from an atomic counter, so the
+// spill buffer is sized by the resident waves, not by the batch, and a length-sorted descriptor
+// table is consumed longest-first.
+constexpr u32 LONG_LDS_BLOCKS = DUMP_GROUP + 1u;  // 17
+
+__host__ __device__ inline PkLayout pk_layout_long(u32 maxfb) {
+    PkLayout l;
+    l.maxfb = maxfb;
+    l.dec_bytes = DUMP_GROUP * DEC_BLOCK;
+    const u32 scratch = 64u * 4u * pk_scratch_words(maxfb), img = 16u * pk_img_stride(maxfb);
+    u32 tabregion = DEC_BLOCK + scratch + img;
+    tabregion = tabregion > (u32)TAB_BYTES ? ((tabregion + 15u) & ~15u) : (u32)TAB_BYTES;
+    l.cp_off = 0;
+    l.img_off = l.dec_bytes + DEC_BLOCK + scratch;
+    l.total = l.dec_bytes + tabregion;
+    return l;
+}
+
+__global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __restrict__ sym, uint8_t* __restrict__ out,
+                                                             const vit_frame_desc* __restrict__ desc,
+                                                             u32 framebits_uniform, long long nframes, PkLayout lay,
+                                                             uint2* spill, u32 spill_blocks, unsigned* counter,
+                                                             u32 ngroups) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* dec = lds;                  // 16 blocks; the 17th (last) lands on the dead table
+    char* tab = lds + lay.dec_bytes;  // [tau][pair][c] -> M; after the ACS: last block, scratch, image
+    u32* img = reinterpret_cast<u32*>(lds + lay.img_off);
+    const u32 lane = threadIdx.x;
+    uint2* wspill = spill + (size_t)blockIdx.x * spill_blocks * 64u + lane;
+
+    // ---- lane constants (same roles as in vit_pk_kernel) ----
+    const u32 l5 = lane & 31u, pair = lane >> 5;
+    Lanes L;
+#pragma unroll
+    for (int rho = 0; rho < 5; rho++) {
+        const u32 i = ((l5 << rho) | (l5 >> (5 - rho))) & 31u;
+        const u32 i0 = i & 1u, i1 = (i >> 1) & 1u, i2 = (i >> 2) & 1u, i3 = (i >> 3) & 1u, i4 = (i >> 4) & 1u;
+        const u32 c = (i1 ^ i2 ^ i4) | ((i0 ^ i1 ^ i2) << 1) | ((i0 ^ i3) << 2);
+        L.toff[rho] = pair * 32u + c * 4u;
+    }
+    Consts C;
+    C.hi = HI;
+    asm volatile("" : "+v"(C.hi));
+    const u32 tau = lane >> 1, pp = lane & 1u;
+    u32 sel[4];
+    {
+        const u32 hb = (tau & 1u) ? 0x0C000C00u : 0x0D000D00u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) sel[k] = hb | (0x00040000u + 0x00010001u * k);
+    }
+
+    for (;;) {
+        u32 grp = 0;
+        if (lane == 0) grp = atomicAdd(counter, 1u);
+        grp = (u32)__builtin_amdgcn_readfirstlane((int)grp);
+        if (grp >= ngroups) break;
+        const long long f0 = (long long)grp * 4;
+        u32 fbits[4];
+        size_t soff[4], ooff[4];
+        u32 maxfb = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const long long f = f0 + k;
+            fbits[k] = 0;
+            soff[k] = ooff[k] = 0;
+            if (f < nframes) {
+                if (desc) {
+                    fbits[k] = desc[f].framebits;
+                    soff[k] = desc[f].sym_offset;
+                    ooff[k] = desc[f].out_offset;
+                    if (fbits[k] > lay.maxfb || (fbits[k] & 7u)) fbits[k] = 0;  // not what the launch was sized for
+                } else {
+                    fbits[k] = framebits_uniform;
+                    soff[k] = (size_t)f * 4u * (framebits_uniform + VIT_TAIL);
+                    ooff[k] = (size_t)f * (framebits_uniform >> 3);
+                }
+            }
+            maxfb = fbits[k] > maxfb ? fbits[k] : maxfb;
+        }
+        if (maxfb == 0) continue;
+        const u32 nblk = (maxfb + VIT_TAIL + 15u) >> 4;
+        const u32 G = nblk > LONG_LDS_BLOCKS ? nblk - LONG_LDS_BLOCKS : 0u;  // spilled blocks (<= spill_blocks)
+        const u32 fstride = pk_img_stride(maxfb);
+        const u32 T_max = maxfb + VIT_TAIL;
+        const u32 a_fb = pp ? fbits[2] : fbits[0], b_fb = pp ? fbits[3] : fbits[1];
+        const u32 a_T = a_fb ? a_fb + VIT_TAIL : 0u, b_T = b_fb ? b_fb + VIT_TAIL : 0u;
+        const u32* a_sym = reinterpret_cast<const u32*>(sym + (pp ? soff[2] : soff[0]));
+        const u32* b_sym = reinterpret_cast<const u32*>(sym + (pp ? soff[3] : soff[1]));
+
+        // ---- forward pass: ACS with history over all blocks ----
+        u32 A = l5 == 0 ? 0u : 0x003F003Fu, B = 0x003F003Fu;
+        u32 acc0 = 0, acc1 = 0;
+        {
+            u32 sa = tau < a_T ? a_sym[tau] : 0u, sb = tau < b_T ? b_sym[tau] : 0u;
+            u32 v = 0;
+            for (u32 rb = 0; rb < nblk; rb++) {
+                if ((rb & 1u) == 0) {
+                    __syncthreads();
+                    prepass(sa, sb, tab, lane, sel);
+                    const u32 tn = (rb + 2u) * 16u + tau;
+                    sa = tn < a_T ? a_sym[tn] : 0u;
+                    sb = tn < b_T ? b_sym[tn] : 0u;
+                    __syncthreads();
+                }
+                steps16<true>(v, A, B, acc0, acc1, tab + (rb & 1u) * 1024u, L, lane, C);
+                if (rb < G) {
+                    wspill[(size_t)rb * 64u] = make_uint2(acc0, acc1);
+                } else {
+                    if (rb + 1u == nblk) __syncthreads();  // the last block lands on the table: all reads done first
+                    *reinterpret_cast<uint2*>(dec + (rb - G) * DEC_BLOCK + lane * 8) = make_uint2(acc0, acc1);
+                }
+                v = v == 4 ? 0 : v + 1;
+            }
+        }
+        __syncthreads();
+        for (u32 i = lane; i < 4u * fstride; i += 64u) img[i] = 0;
+
+        // ---- traceback: LDS tail, then the spilled blocks 16 at a time from the top ----
+        const u32 fi = lane >> 4;
+        const u32 t_fb = fi == 0 ? fbits[0] : fi == 1 ? fbits[1] : fi == 2 ? fbits[2] : fbits[3];
+        const u32 t_T = t_fb ? t_fb + VIT_TAIL : 0u;
+        u32* scratch = reinterpret_cast<u32*>(tab + DEC_BLOCK) + lane * pk_scratch_words(lay.maxfb);
+        const u32 t_lo = G * 16u;
+        u32 P_part = traceback_part(dec, scratch, img, fstride, lane, t_lo > VIT_TAIL ? t_lo : VIT_TAIL, t_T, T_max, G,
+                                    P_ZERO);
+        for (u32 g1 = G; g1 > 0;) {
+            const u32 g0 = g1 > DUMP_GROUP ? g1 - DUMP_GROUP : 0u;
+            uint2 d[DUMP_GROUP];
+#pragma unroll
+            for (u32 k = 0; k < DUMP_GROUP; k++)
+                d[k] = (g0 + k < g1) ? wspill[(size_t)(g0 + k) * 64u] : make_uint2(0u, 0u);
+            __syncthreads();
+#pragma unroll
+            for (u32 k = 0; k < DUMP_GROUP; k++)
+                *reinterpret_cast<uint2*>(dec + k * DEC_BLOCK + lane * 8) = d[k];
+            __syncthreads();
+            const u32 tsg = g0 ? g0 * 16u : VIT_TAIL, tend = g1 * 16u;
+            const u32 te = t_T < tend ? t_T : tend, te_max = T_max < tend ? T_max : tend;
+            const u32 P_top = t_T > tend ? P_part : P_ZERO;
+            P_part = traceback_part(dec, scratch, img, fstride, lane, tsg, te, te_max, g0, P_top);
+            g1 = g0;
+        }
+        __syncthreads();
+
+        // ---- output bytes, MSB first (deconvolve.cpp:432-433) ----
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 nbytes = fbits[k] >> 3;
+            uint8_t* o = out + ooff[k];
+            if (((ooff[k] | nbytes) & 3u) == 0) {
+                for (u32 m = lane; m < (nbytes >> 2); m += 64u)
+                    reinterpret_cast<u32*>(o)[m] = __builtin_bswap32(__builtin_bitreverse32(img[k * fstride + m]));
+            } else {
+                for (u32 j = lane; j < nbytes; j += 64u) {
+                    const u32 byte = (img[k * fstride + (j >> 2)] >> (8u * (j & 3u))) & 0xFFu;
+                    o[j] = (uint8_t)(__builtin_bitreverse32(byte) >> 24);
+                }
+            }
+        }
+        __syncthreads();  // the image is read before the next group's pre-pass reuses the region
+    }
+}
+
 constexpr u32 PK_MAX_FRAMEBITS = VIT_MAX_FRAMEBITS;
 
 }  // namespace
 
 bool vit_pk_supported(uint32_t max_framebits) {
-    return max_framebits >= 8 && max_framebits <= PK_MAX_FRAMEBITS && (max_framebits % 8u) == 0 &&
-           pk_layout(max_framebits).total <= 160u * 1024u;
+    if (max_framebits < 8 || max_framebits > PK_MAX_FRAMEBITS || (max_framebits % 8u) != 0) return false;
+    const u32 nblk = (max_framebits + VIT_TAIL + 15u) >> 4;
+    return (nblk <= SEG_BLOCKS ? pk_layout(max_framebits) : pk_layout_long(max_framebits)).total <= 160u * 1024u;
 }
+
+// Spill buffer of the long-frame kernel: per calling thread, grown on demand, reuse ordered by an event
+// (a thread may alternate between streams).  [0,256) = the group counter, then grid x spill_blocks x 512 B.
+struct SpillCtx {
+    void* buf = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    int dev = -1;
+    ~SpillCtx() {
+        if (buf) (void)hipFree(buf);
+        if (ev) (void)hipEventDestroy(ev);
+    }
+};
+thread_local SpillCtx t_spill;
 
 hipError_t vit_launch_pk(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_desc* d_desc, uint32_t framebits,
                          uint32_t max_framebits, int64_t nframes, hipStream_t stream) {
@@ -645,19 +830,49 @@ hipError_t vit_launch_pk(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_d
         attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(vit_pk_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (attr_err == hipSuccess)
-            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(vit_pk_kernel<true>),
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(vit_pk_long_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     if (attr_err != hipSuccess) return attr_err;
     const long long groups = (nframes + 3) / 4;
     if (groups > 0x7FFFFFFFLL) return hipErrorInvalidValue;
-    const PkLayout lay = pk_layout(max_framebits);
-    const bool multi = ((max_framebits + VIT_TAIL + 15u) >> 4) > SEG_BLOCKS;
-    if (multi)
-        hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)groups), dim3(64), lay.total, stream, d_sym, d_out,
-                           d_desc, framebits, (long long)nframes, lay);
-    else
+    const u32 nblk = (max_framebits + VIT_TAIL + 15u) >> 4;
+    if (nblk <= SEG_BLOCKS) {
+        const PkLayout lay = pk_layout(max_framebits);
         hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)groups), dim3(64), lay.total, stream, d_sym, d_out,
                            d_desc, framebits, (long long)nframes, lay);
-    return hipGetLastError();
+        return hipGetLastError();
+    }
+    // long frames: persistent workgroups + spill buffer
+    const PkLayout lay = pk_layout_long(max_framebits);
+    int dev = 0, cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+    u32 per_cu = (160u * 1024u) / lay.total;
+    if (per_cu > 16u) per_cu = 16u;  // 4 waves per SIMD (launch bounds)
+    long long grid = (long long)per_cu * cus;
+    if (grid > groups) grid = groups;
+    const u32 spill_blocks = nblk - LONG_LDS_BLOCKS;
+    const size_t need = 256u + (size_t)grid * spill_blocks * DEC_BLOCK;
+    SpillCtx& sc = t_spill;
+    if (sc.dev != dev || sc.cap < need) {
+        if (sc.buf) (void)hipFree(sc.buf);  // synchronises with the kernels still using it
+        sc.buf = nullptr;
+        sc.cap = 0;
+        if (sc.ev) (void)hipEventDestroy(sc.ev);
+        sc.ev = nullptr;
+        if ((e = hipMalloc(&sc.buf, need + need / 4)) != hipSuccess) return e;
+        sc.cap = need + need / 4;
+        sc.dev = dev;
+        if ((e = hipEventCreateWithFlags(&sc.ev, hipEventDisableTiming)) != hipSuccess) return e;
+    } else if ((e = hipStreamWaitEvent(stream, sc.ev, 0)) != hipSuccess) {
+        return e;
+    }
+    if ((e = hipMemsetAsync(sc.buf, 0, 256, stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL(vit_pk_long_kernel, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out, d_desc,
+                       framebits, (long long)nframes, lay, reinterpret_cast<uint2*>((char*)sc.buf + 256), spill_blocks,
+                       reinterpret_cast<unsigned*>(sc.buf), (u32)groups);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    return hipEventRecord(sc.ev, stream);
 }

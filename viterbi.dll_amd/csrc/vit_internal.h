@@ -7,6 +7,7 @@
 
 #define VIT_MAX_FRAMEBITS 9216u  // deconvolve.cpp:93,127 (384*24)
 #define VIT_TAIL 6u              // K-1 tail steps
+#define VIT_SORT_BINS (VIT_MAX_FRAMEBITS / 8u + 1u)  // counting-sort keys framebits/8
 
 // Wave-per-frame kernel (lane = trellis state); any even framebits <= 9216.
 hipError_t vit_launch_wave(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_desc* d_desc,
@@ -18,6 +19,9 @@ bool vit_pk_supported(uint32_t max_framebits);
 hipError_t vit_launch_pk(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_desc* d_desc,
                          uint32_t framebits, uint32_t max_framebits, int64_t nframes,
                          hipStream_t stream);
+// Length-sorted (longest first) copy of a device descriptor table; d_bins = 2*VIT_SORT_BINS words of scratch.
+hipError_t vit_sort_descs_launch(const vit_frame_desc* d_desc, vit_frame_desc* d_sorted, int64_t nframes,
+                                 uint32_t max_framebits, unsigned* d_bins, hipStream_t stream);
 // u32 -> u8 narrowing (low byte), the reference ABI's symbol format to the device format.
 hipError_t vit_launch_pack(const uint32_t* d_sym32, uint8_t* d_sym8, int64_t nsym,
                            hipStream_t stream);

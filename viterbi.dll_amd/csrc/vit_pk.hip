@@ -47,6 +47,7 @@
 // Replaces, from scratch: decon_avx2 / Butterfly256 (deconvolve.cpp:334-387,
 // 514-526), Load8Syms256 (:219-228), Renormalize256 (:407-412), ChainBack
 // (:416-435), chainback.inc:18-41 and const.asm:19-63.
+#include <cstdlib>
 #include <mutex>
 
 #include "vit_internal.h"
@@ -806,19 +807,28 @@ bool vit_pk_supported(uint32_t max_framebits) {
     return (nblk <= SEG_BLOCKS ? pk_layout(max_framebits) : pk_layout_long(max_framebits)).total <= 160u * 1024u;
 }
 
-// Spill buffer of the long-frame kernel: per calling thread, grown on demand, reuse ordered by an event
-// (a thread may alternate between streams).  [0,256) = the group counter, then grid x spill_blocks x 512 B.
-struct SpillCtx {
+// Per-thread device scratch of the launcher, grown on demand; its reuse is ordered by an event (a
+// thread may alternate between streams).  Layout: [0,256) group counter of the persistent kernel,
+// [256,16K) counting-sort bins, then the length-sorted descriptor copy, then the spill slices
+// (grid x spill_blocks x 512 B).
+struct ScratchCtx {
     void* buf = nullptr;
     size_t cap = 0;
     hipEvent_t ev = nullptr;
     int dev = -1;
-    ~SpillCtx() {
+    ~ScratchCtx() {
         if (buf) (void)hipFree(buf);
         if (ev) (void)hipEventDestroy(ev);
     }
 };
-thread_local SpillCtx t_spill;
+thread_local ScratchCtx t_scratch;
+constexpr size_t SCRATCH_HDR = 16384;
+constexpr int64_t SORT_MIN_FRAMES = 16;  // below this a table is not worth three extra launches
+
+bool sort_enabled() {
+    static const bool on = getenv("VITERBI_AMD_NO_SORT") == nullptr;
+    return on;
+}
 
 hipError_t vit_launch_pk(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_desc* d_desc, uint32_t framebits,
                          uint32_t max_framebits, int64_t nframes, hipStream_t stream) {
@@ -837,25 +847,32 @@ hipError_t vit_launch_pk(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_d
     const long long groups = (nframes + 3) / 4;
     if (groups > 0x7FFFFFFFLL) return hipErrorInvalidValue;
     const u32 nblk = (max_framebits + VIT_TAIL + 15u) >> 4;
-    if (nblk <= SEG_BLOCKS) {
+    const bool is_long = nblk > SEG_BLOCKS;
+    const bool sort = d_desc != nullptr && nframes >= SORT_MIN_FRAMES && sort_enabled();
+    if (!is_long && !sort) {
         const PkLayout lay = pk_layout(max_framebits);
         hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)groups), dim3(64), lay.total, stream, d_sym, d_out,
                            d_desc, framebits, (long long)nframes, lay);
         return hipGetLastError();
     }
-    // long frames: persistent workgroups + spill buffer
-    const PkLayout lay = pk_layout_long(max_framebits);
-    int dev = 0, cus = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-    u32 per_cu = (160u * 1024u) / lay.total;
-    if (per_cu > 16u) per_cu = 16u;  // 4 waves per SIMD (launch bounds)
-    long long grid = (long long)per_cu * cus;
-    if (grid > groups) grid = groups;
-    const u32 spill_blocks = nblk - LONG_LDS_BLOCKS;
-    const size_t need = 256u + (size_t)grid * spill_blocks * DEC_BLOCK;
-    SpillCtx& sc = t_spill;
+    const PkLayout lay = is_long ? pk_layout_long(max_framebits) : pk_layout(max_framebits);
+    hipError_t e;
+    long long grid = groups;
+    u32 spill_blocks = 0;
+    int dev = 0;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+    if (is_long) {  // persistent workgroups: as many as fit the chip
+        int cus = 0;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+        u32 per_cu = (160u * 1024u) / lay.total;
+        if (per_cu > 16u) per_cu = 16u;  // 4 waves per SIMD (launch bounds)
+        grid = (long long)per_cu * cus;
+        if (grid > groups) grid = groups;
+        spill_blocks = nblk - LONG_LDS_BLOCKS;
+    }
+    const size_t desc_bytes = sort ? (((size_t)nframes * sizeof(vit_frame_desc) + 255u) & ~(size_t)255u) : 0u;
+    const size_t need = SCRATCH_HDR + desc_bytes + (size_t)grid * spill_blocks * DEC_BLOCK;
+    ScratchCtx& sc = t_scratch;
     if (sc.dev != dev || sc.cap < need) {
         if (sc.buf) (void)hipFree(sc.buf);  // synchronises with the kernels still using it
         sc.buf = nullptr;
@@ -869,10 +886,23 @@ hipError_t vit_launch_pk(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_d
     } else if ((e = hipStreamWaitEvent(stream, sc.ev, 0)) != hipSuccess) {
         return e;
     }
-    if ((e = hipMemsetAsync(sc.buf, 0, 256, stream)) != hipSuccess) return e;
-    hipLaunchKernelGGL(vit_pk_long_kernel, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out, d_desc,
-                       framebits, (long long)nframes, lay, reinterpret_cast<uint2*>((char*)sc.buf + 256), spill_blocks,
-                       reinterpret_cast<unsigned*>(sc.buf), (u32)groups);
+    char* base = static_cast<char*>(sc.buf);
+    if (sort) {
+        vit_frame_desc* sorted = reinterpret_cast<vit_frame_desc*>(base + SCRATCH_HDR);
+        if ((e = vit_sort_descs_launch(d_desc, sorted, nframes, max_framebits, reinterpret_cast<unsigned*>(base + 256),
+                                       stream)) != hipSuccess)
+            return e;
+        d_desc = sorted;
+    }
+    if (is_long) {
+        if ((e = hipMemsetAsync(base, 0, 256, stream)) != hipSuccess) return e;
+        hipLaunchKernelGGL(vit_pk_long_kernel, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out, d_desc,
+                           framebits, (long long)nframes, lay, reinterpret_cast<uint2*>(base + SCRATCH_HDR + desc_bytes),
+                           spill_blocks, reinterpret_cast<unsigned*>(base), (u32)groups);
+    } else {
+        hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)groups), dim3(64), lay.total, stream, d_sym, d_out,
+                           d_desc, framebits, (long long)nframes, lay);
+    }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     return hipEventRecord(sc.ev, stream);
 }

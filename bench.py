@@ -33,14 +33,18 @@ POLYS = (109, 79, 83, 109)  # viterbi-benchmark.cpp:64
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def make_frames(nframes, framebits, seed, device, ebn0_db=3.0, return_bits=False):
+def make_frames(nframes, framebits, seed, device, ebn0_db=3.0, return_bits=False, payload_bits=None):
     """Reference-style synthetic input (viterbi-benchmark.cpp:293-311): random bits ->
     DAB mother code -> AWGN at Eb/N0 = 3 dB, sample = 127.5 + 32*N(+-gain,1), clip 0..255.
-    Built on the GPU with a seeded torch generator; returns uint8 [nframes, 4*(framebits+6)]."""
+    Built on the GPU with a seeded torch generator; returns uint8 [nframes, 4*(framebits+6)].
+    payload_bits (int32 [nframes, framebits], 0/1) replaces the random payload."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     T = framebits + TAIL
-    bits = torch.randint(0, 2, (nframes, framebits), generator=g, device=device, dtype=torch.int32)
+    if payload_bits is not None:
+        bits = payload_bits.to(device=device, dtype=torch.int32)
+    else:
+        bits = torch.randint(0, 2, (nframes, framebits), generator=g, device=device, dtype=torch.int32)
     bits = torch.cat([bits, torch.zeros((nframes, TAIL), dtype=torch.int32, device=device)], dim=1)
     # sr(t) = last 7 input bits, newest in bit 0
     padded = torch.cat([torch.zeros((nframes, 6), dtype=torch.int32, device=device), bits], dim=1)

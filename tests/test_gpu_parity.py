@@ -160,16 +160,28 @@ def test_deconvolve_micro_batching(V, O, torch_cuda):
     assert not errs
 
 
-def test_u32_ingest_path(V, O, torch_cuda):
+@pytest.mark.parametrize("framebits,n", [(768, 50), (3072, 9), (24, 5)])
+def test_u32_ingest_path(V, O, torch_cuda, framebits, n):
+    """the reference ABI's u32-per-symbol format resident on the device (only the low byte counts,
+    deconvolve.cpp:158-165): read in place by the packed kernels (short and long frames), narrowed by the
+    ingest kernel for the wave kernel and for a buffer that is not 16-byte aligned"""
     torch = torch_cuda
-    framebits, n = 768, 50
     sym = _mixed_input(O, n, framebits, seed=77)
     want = O.decode_batch(framebits, sym)
-    d32 = torch.from_numpy(sym.astype(np.int64)).to(torch.int32).cuda()
-    d_out = torch.zeros((n, framebits // 8), dtype=torch.uint8, device="cuda")
-    V.decode_batch_dev_u32(d32, d_out, framebits, n)
-    torch.cuda.synchronize()
-    assert np.array_equal(d_out.cpu().numpy(), want)
+    junk = np.random.default_rng(5).integers(0, 1 << 24, sym.shape, dtype=np.int64) << 8  # upper bytes must be ignored
+    host32 = ((sym.astype(np.int64) | junk) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+    flat = torch.zeros(host32.size + 4, dtype=torch.int32, device="cuda")
+    for kernel, shift in ((0, 0), (0, 1), (1, 0), (2, 0)):
+        d32 = flat[shift:shift + host32.size]
+        d32.copy_(torch.from_numpy(host32.reshape(-1)))
+        d_out = torch.zeros((n, framebits // 8), dtype=torch.uint8, device="cuda")
+        old = V.set_kernel(kernel)
+        try:
+            V.decode_batch_dev_u32(d32, d_out, framebits, n)
+            torch.cuda.synchronize()
+        finally:
+            V.set_kernel(old)
+        assert np.array_equal(d_out.cpu().numpy(), want), (kernel, shift)
 
 
 @pytest.mark.parametrize("kernel", [0, 1, 2])

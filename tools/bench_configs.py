@@ -95,3 +95,50 @@ for rsdims in (24, 12, 4):
     print(json.dumps({"case": "config5 RS", "rsdims": rsdims, "superframes": nsf, "ms": round(ms, 4),
                       "GB_s_in_plus_out": round(nsf * 230 * rsdims / ms / 1e6, 1),
                       "superframes_per_s": round(nsf / ms * 1e3), "parity_ok": ok}), flush=True)
+
+# ---- config 5, whole pipeline: 16384 superframes x (5 x deconvolve -> RScheckSuperframe), RSDims = 24 ----
+# payload = valid RS(120,110) codewords column-wise (own encoder), mother code, AWGN at Eb/N0 = 3 dB;
+# 64 distinct superframes of payload tiled over the batch, independent noise on every frame.
+for rsdims in (24, 12):
+    nsf, base_n = 16384, 64
+    fb = 192 * rsdims
+    rng = np.random.default_rng(500 + rsdims)
+    blocks = np.empty((base_n, 120, rsdims), np.uint8)
+    for s_ in range(base_n):
+        for j in range(rsdims):
+            blocks[s_, :, j] = O.rs_encode(rng.integers(0, 256, 110, dtype=np.uint8))
+    bits = np.unpackbits(blocks.reshape(base_n, -1), axis=1).reshape(base_n * 5, fb)
+    pb = torch.from_numpy(bits.astype(np.int32)).to(dev).repeat(nsf // base_n, 1)
+    sym = make_frames(nsf * 5, fb, seed=7, device=dev, payload_bits=pb)
+    del pb
+    d_work = torch.zeros((nsf, 120 * rsdims), dtype=torch.uint8, device=dev)
+    d_out = torch.zeros((nsf, 110 * rsdims), dtype=torch.uint8, device=dev)
+    d_ret = torch.zeros(nsf, dtype=torch.int32, device=dev)
+    ms = timeit(lambda: V.dabplus_superframes_dev(sym, d_work, d_out, d_ret, rsdims, nsf), steps=5, warm=1)
+    ms_dec = timeit(lambda: V.decode_batch_dev(sym, d_work, fb, nsf * 5), steps=5, warm=1)
+    k = 32  # parity of both stages on a sample of superframes
+    dec_ref = O.decode_batch(fb, sym[:5 * k].cpu().numpy(), nthreads=16).reshape(k, 120 * rsdims)
+    ret_ref, out_ref = O.rs_check_batch(dec_ref, rsdims)
+    ok = bool(np.array_equal(d_work[:k].cpu().numpy(), dec_ref)) and bool(np.array_equal(d_ret[:k].cpu().numpy(), ret_ref)) \
+        and bool(np.array_equal(d_out[:k].cpu().numpy()[ret_ref >= 0], out_ref[ret_ref >= 0]))
+    ret = d_ret.cpu().numpy()
+    print(json.dumps({"case": "config5 pipeline decode x5 + RS", "rsdims": rsdims, "superframes": nsf, "framebits": fb,
+                      "ms": round(ms, 3), "ms_decode_only": round(ms_dec, 3),
+                      "superframes_per_s": round(nsf / ms * 1e3), "decoded_Mbit_s": round(nsf * 5 * fb / ms / 1e3, 1),
+                      "superframes_failed": int((ret < 0).sum()), "symbols_corrected": int(ret[ret > 0].sum()),
+                      "parity_sample_ok": ok}), flush=True)
+    del sym, d_work, d_out
+
+# ---- config 4 at N = 1: a stream of 4M FIC frames (13 GB of u8 symbols) resident on one GPU, decoded in
+# 64 chunks of 65536 frames; the 8-GPU round-robin variant is bench.py --mode scatter ----
+n_total, chunk = 4 * 1024 * 1024, 65536
+base = make_frames(chunk * 4, 768, seed=4, device=dev)          # 4 distinct chunks of noise ...
+stream = base.repeat(n_total // (chunk * 4), 1)                 # ... tiled to 13.0 GB
+out = torch.zeros((n_total, 96), dtype=torch.uint8, device=dev)
+def run_stream():
+    V.decode_batch_dev(stream, out, 768, n_total)
+ms = timeit(run_stream, steps=3, warm=1)
+want = O.decode_batch(768, stream[:256].cpu().numpy(), nthreads=16)
+ok = bool(np.array_equal(out[:256].cpu().numpy(), want)) and bool(torch.equal(out[:chunk * 4], out[-chunk * 4:]))
+print(json.dumps({"case": "config4 at N=1: 4M FIC frames resident (13.0 GB), one launch", "frames": n_total,
+                  "ms": round(ms, 2), "Mbit_s": round(n_total * 768 / ms / 1e3, 1), "parity_sample_ok": ok}), flush=True)

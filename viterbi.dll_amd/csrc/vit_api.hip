@@ -101,7 +101,8 @@ void ensure_init() { std::call_once(g_once, probe_devices); }
 // ---- per-thread context: stream + staging (README.md:56: callers are threads) ----
 struct ThreadCtx {
     hipStream_t stream = nullptr;
-    void* h_pin = nullptr;   size_t h_cap = 0;   // pinned host staging
+    void* h_pin = nullptr;   size_t h_cap = 0;   // pinned host staging (mapped: h_pin_dev is its device view)
+    void* h_pin_dev = nullptr;
     void* d_in = nullptr;    size_t din_cap = 0; // device input (u32 or u8 / RS block)
     void* d_sym8 = nullptr;  size_t d8_cap = 0;  // packed symbols
     void* d_out = nullptr;   size_t dout_cap = 0;
@@ -156,9 +157,10 @@ int grow_dev(void** p, size_t* cap, size_t need) {
 int grow_pin(size_t need) {
     if (t_ctx.h_cap >= need) return VIT_OK;
     if (t_ctx.h_pin) HIPCHK(hipHostFree(t_ctx.h_pin));
-    t_ctx.h_pin = nullptr; t_ctx.h_cap = 0;
+    t_ctx.h_pin = nullptr; t_ctx.h_pin_dev = nullptr; t_ctx.h_cap = 0;
     size_t sz = need < 65536 ? 65536 : need + need / 4;
-    HIPCHK(hipHostMalloc(&t_ctx.h_pin, sz, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(&t_ctx.h_pin, sz, hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer(&t_ctx.h_pin_dev, t_ctx.h_pin, 0));
     t_ctx.h_cap = sz;
     return VIT_OK;
 }
@@ -166,23 +168,45 @@ int grow_pin(size_t need) {
 bool valid_framebits(uint32_t fb) { return fb <= VIT_MAX_FRAMEBITS && (fb & 1u) == 0; }
 
 // the analogue of setupdll.cpp:195-270's dispatcher: choose the kernel for a batch
-int launch_decode(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_desc* d_desc, uint32_t framebits,
-                  uint32_t max_framebits, int64_t nframes, hipStream_t s) {
+bool packed_kernel_selected(const vit_frame_desc* d_desc, uint32_t framebits, uint32_t max_framebits, bool* forced_bad) {
     const int k = g_kernel.load();
     const bool pk_ok = (max_framebits % 8u) == 0 && (!d_desc ? (framebits % 8u) == 0 : true) &&
                        vit_pk_supported(max_framebits);
-    const bool use_pk = (k == 2) ? pk_ok : (k == 1 ? false : pk_ok);
-    if (k == 2 && !pk_ok) {
+    if (forced_bad) *forced_bad = (k == 2 && !pk_ok);
+    return k == 1 ? false : pk_ok;
+}
+int launch_decode(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_desc* d_desc, uint32_t framebits,
+                  uint32_t max_framebits, int64_t nframes, hipStream_t s) {
+    bool forced_bad = false;
+    const bool use_pk = packed_kernel_selected(d_desc, framebits, max_framebits, &forced_bad);
+    if (forced_bad) {
         set_err("packed kernel does not support framebits=%u", max_framebits);
         return VIT_ERR_ARG;
     }
-    hipError_t e = use_pk ? vit_launch_pk(d_sym, d_out, d_desc, framebits, max_framebits, nframes, s)
+    hipError_t e = use_pk ? vit_launch_pk(d_sym, false, d_out, d_desc, framebits, max_framebits, nframes, s)
                           : vit_launch_wave(d_sym, d_out, d_desc, framebits, max_framebits, nframes, s);
     if (e != hipSuccess) {
         set_err("kernel launch failed: %s", hipGetErrorString(e));
         return VIT_ERR_HIP;
     }
     return VIT_OK;
+}
+// Symbols still in the reference ABI's u32 format (deconvolve.cpp:158-165).  The packed kernels read them
+// directly (narrowing fused into their pre-pass); otherwise they are narrowed into `d_scratch8` first.
+int launch_decode_u32(const uint32_t* d_sym32, uint8_t* d_scratch8, uint8_t* d_out, const vit_frame_desc* d_desc,
+                      uint32_t framebits, uint32_t max_framebits, int64_t nframes, int64_t nsym, hipStream_t s) {
+    if (packed_kernel_selected(d_desc, framebits, max_framebits, nullptr) &&
+        (reinterpret_cast<uintptr_t>(d_sym32) & 15u) == 0) {
+        hipError_t e = vit_launch_pk(d_sym32, true, d_out, d_desc, framebits, max_framebits, nframes, s);
+        if (e != hipSuccess) {
+            set_err("kernel launch failed: %s", hipGetErrorString(e));
+            return VIT_ERR_HIP;
+        }
+        return VIT_OK;
+    }
+    hipError_t e = vit_launch_pack(d_sym32, d_scratch8, nsym, s);
+    if (e != hipSuccess) { set_err("pack launch failed: %s", hipGetErrorString(e)); return VIT_ERR_HIP; }
+    return launch_decode(d_scratch8, d_out, d_desc, framebits, max_framebits, nframes, s);
 }
 
 int hip_device_ready() {
@@ -253,11 +277,9 @@ struct Batcher {
         hipStream_t s = t_ctx.stream;
         HIPCHK(hipMemcpyAsync(t_ctx.d_in, pin, nsym * 4, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(d_desc, h_d, desc_bytes, hipMemcpyHostToDevice, s));
-        hipError_t e = vit_launch_pack((const uint32_t*)t_ctx.d_in, (uint8_t*)t_ctx.d_sym8, (int64_t)nsym, s);
-        if (e != hipSuccess) { set_err("pack launch failed: %s", hipGetErrorString(e)); return VIT_ERR_HIP; }
-        // mixed parities of framebits/8 are fine for the packed kernel; odd framebits go one by one below
-        rc = launch_decode((const uint8_t*)t_ctx.d_sym8, (uint8_t*)t_ctx.d_out, (const vit_frame_desc*)d_desc, 0, maxfb,
-                           (int64_t)b.size(), s);
+        // sym_offset counts symbols: the same table addresses the u32 buffer and its narrowed copy
+        rc = launch_decode_u32((const uint32_t*)t_ctx.d_in, (uint8_t*)t_ctx.d_sym8, (uint8_t*)t_ctx.d_out,
+                               (const vit_frame_desc*)d_desc, 0, maxfb, (int64_t)b.size(), (int64_t)nsym, s);
         if (rc != VIT_OK) return rc;
         HIPCHK(hipMemcpyAsync(h_out, t_ctx.d_out, nout, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -375,18 +397,20 @@ int vit_decode_batch_dev_u32(const uint32_t* d_symbols_u32, uint8_t* d_decoded, 
         return VIT_ERR_ARG;
     }
     if (framebits == 0 || nframes == 0) return VIT_OK;
+    const size_t nsym = (size_t)nframes * 4u * (framebits + VIT_TAIL);
+    if (packed_kernel_selected(nullptr, framebits, framebits, nullptr) &&
+        (reinterpret_cast<uintptr_t>(d_symbols_u32) & 15u) == 0)  // read in place: no scratch, no extra launch
+        return launch_decode_u32(d_symbols_u32, nullptr, d_decoded, nullptr, framebits, framebits, nframes, (int64_t)nsym,
+                                 (hipStream_t)stream);
     int rc = ctx_prepare();
     if (rc != VIT_OK) return rc;
-    const size_t nsym = (size_t)nframes * 4u * (framebits + VIT_TAIL);
     rc = grow_dev(&t_ctx.d_sym8, &t_ctx.d8_cap, nsym);  // may synchronise the device (hipMalloc)
     if (rc != VIT_OK) return rc;
     // the narrowed symbols live in this thread's scratch buffer: order its reuse across the caller's streams
     if (!t_ctx.scratch_ev) HIPCHK(hipEventCreateWithFlags(&t_ctx.scratch_ev, hipEventDisableTiming));
     else HIPCHK(hipStreamWaitEvent((hipStream_t)stream, t_ctx.scratch_ev, 0));
-    hipError_t e = vit_launch_pack(d_symbols_u32, (uint8_t*)t_ctx.d_sym8, (int64_t)nsym, (hipStream_t)stream);
-    if (e != hipSuccess) { set_err("pack launch failed: %s", hipGetErrorString(e)); return VIT_ERR_HIP; }
-    rc = launch_decode((const uint8_t*)t_ctx.d_sym8, d_decoded, nullptr, framebits, framebits, nframes,
-                       (hipStream_t)stream);
+    rc = launch_decode_u32(d_symbols_u32, (uint8_t*)t_ctx.d_sym8, d_decoded, nullptr, framebits, framebits, nframes,
+                           (int64_t)nsym, (hipStream_t)stream);
     if (rc != VIT_OK) return rc;
     HIPCHK(hipEventRecord(t_ctx.scratch_ev, (hipStream_t)stream));
     return VIT_OK;
@@ -458,9 +482,7 @@ static int deconvolve_impl(unsigned int framebits, unsigned int* symbols, unsign
     const size_t nsym = 4u * ((size_t)framebits + VIT_TAIL);
     const size_t out_sz = (framebits + 7u) >> 3;
     int rc;
-    if ((rc = grow_pin(nsym * 4 + out_sz + 64)) != VIT_OK || (rc = grow_dev(&t_ctx.d_in, &t_ctx.din_cap, nsym * 4)) != VIT_OK ||
-        (rc = grow_dev(&t_ctx.d_sym8, &t_ctx.d8_cap, nsym)) != VIT_OK ||
-        (rc = grow_dev(&t_ctx.d_out, &t_ctx.dout_cap, out_sz)) != VIT_OK) {
+    if ((rc = grow_pin(nsym * 4 + out_sz + 64)) != VIT_OK || (rc = grow_dev(&t_ctx.d_sym8, &t_ctx.d8_cap, nsym)) != VIT_OK) {
         g_fault.store(1);
         return 1;
     }
@@ -469,20 +491,18 @@ static int deconvolve_impl(unsigned int framebits, unsigned int* symbols, unsign
         g_fault.store(1);
         return 1;
     };
+    // Zero-copy staging: the pinned buffer is mapped into the device's address space, so the decode
+    // kernel reads the caller's u32 symbols straight from host memory (12 KB over PCIe, narrowing fused
+    // into its pre-pass) and writes its framebits/8 bytes straight back - no hipMemcpy round trips, one
+    // launch, one sync.
     hipError_t e;
     unsigned char* h_out = (unsigned char*)t_ctx.h_pin + nsym * 4;
     memcpy(t_ctx.h_pin, symbols, nsym * 4);
-    if ((e = hipMemcpyAsync(t_ctx.d_in, t_ctx.h_pin, nsym * 4, hipMemcpyHostToDevice, t_ctx.stream)) != hipSuccess)
-        return fail("H2D", e);
-    if ((e = vit_launch_pack((const uint32_t*)t_ctx.d_in, (uint8_t*)t_ctx.d_sym8, (int64_t)nsym, t_ctx.stream)) != hipSuccess)
-        return fail("pack", e);
-    if (launch_decode((const uint8_t*)t_ctx.d_sym8, (uint8_t*)t_ctx.d_out, nullptr, framebits, framebits, 1,
-                      t_ctx.stream) != VIT_OK) {
+    if (launch_decode_u32((const uint32_t*)t_ctx.h_pin_dev, (uint8_t*)t_ctx.d_sym8, (uint8_t*)t_ctx.h_pin_dev + nsym * 4,
+                          nullptr, framebits, framebits, 1, (int64_t)nsym, t_ctx.stream) != VIT_OK) {
         g_fault.store(1);
         return 1;
     }
-    if ((e = hipMemcpyAsync(h_out, t_ctx.d_out, out_sz, hipMemcpyDeviceToHost, t_ctx.stream)) != hipSuccess)
-        return fail("D2H", e);
     if ((e = hipStreamSynchronize(t_ctx.stream)) != hipSuccess) return fail("sync", e);
     memcpy(decodedBits, h_out, out_sz);
     return 0;

@@ -16,7 +16,9 @@ hipError_t vit_launch_wave(const uint8_t* d_sym, uint8_t* d_out, const vit_frame
 // Packed kernel: 4 frames per wavefront, 2 states x 2 frames per lane register.
 // Needs framebits % 8 == 0 and 4 frames' decisions to fit the LDS budget.
 bool vit_pk_supported(uint32_t max_framebits);
-hipError_t vit_launch_pk(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_desc* d_desc,
+// sym32: d_symbols holds the reference ABI's u32-per-symbol format (16-byte aligned; sym_offset
+// then counts symbols); the narrowing to the low byte is fused into the kernel's pre-pass.
+hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, const vit_frame_desc* d_desc,
                          uint32_t framebits, uint32_t max_framebits, int64_t nframes,
                          hipStream_t stream);
 // Length-sorted (longest first) copy of a device descriptor table; d_bins = 2*VIT_SORT_BINS words of scratch.

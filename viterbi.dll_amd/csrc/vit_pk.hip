@@ -29,9 +29,9 @@
 // 49 blocks (784 steps) the first 32 blocks of history stay in VGPRs (two 32-dword
 // register arrays indexed with s_set_gpr_idx), 16 go to LDS and the last one to the
 // start of the then-dead metric table: 10 KB of LDS per wave, 16 waves per CU.
-// Longer frames run in segments: a forward pass without history checkpoints the
-// metrics at segment boundaries, then the segments are recomputed with history and
-// traced back last to first.
+// Longer frames (vit_pk_long_kernel): same forward pass, but every block except the last 17 is
+// spilled to a per-workgroup slice of HBM (8 B per frame-step each way - the path is VALU-bound and
+// HBM has >90 % headroom) and reloaded 16 blocks at a time for the traceback.
 //
 // Traceback.  Per segment three parts (LDS tail, then the register blocks 16 at a
 // time through the same LDS region), each blocked and speculative: lane = (frame,
@@ -95,6 +95,9 @@ struct Lanes {
 #endif
 #ifndef VIT_K3
 #define VIT_K3 0
+#endif
+#ifndef VIT_PRIO
+#define VIT_PRIO 1  /* measured: ~1 % on the 65536-frame batch */
 #endif
 template <int J>
 DEV void exchange(u32& A, u32& B, u32 N0, u32 N1, u32 lane) {
@@ -246,6 +249,19 @@ DEV void prepass(u32 sa, u32 sb, char* tab, u32 lane, const u32 (&sel)[4]) {
                         __builtin_amdgcn_perm(bhi, ahi, sel[2]), __builtin_amdgcn_perm(bhi, ahi, sel[3]));
 }
 
+// The 4 soft symbols of step t of one frame as 4 bytes.  SYM32 = the reference ABI's format (one u32 per
+// symbol, low byte used: deconvolve.cpp:158-165) read straight from memory - the ingest narrowing fused
+// into the pre-pass (16 B per step instead of 4, no intermediate u8 buffer).
+template <bool SYM32>
+DEV u32 load_step(const uint8_t* frame, u32 t) {
+    if constexpr (!SYM32) {
+        return reinterpret_cast<const u32*>(frame)[t];
+    } else {
+        const uint4 v = reinterpret_cast<const uint4*>(frame)[t];
+        return __builtin_amdgcn_perm(v.y, v.x, 0x0C0C0400u) | __builtin_amdgcn_perm(v.w, v.z, 0x04000C0Cu);
+    }
+}
+
 typedef u32 v32u __attribute__((ext_vector_type(32)));
 constexpr u32 VREG_BLOCKS = 32;  // decision blocks that can stay in VGPRs (2 x 32 dwords)
 
@@ -258,9 +274,7 @@ constexpr u32 SEG_BLOCKS = VREG_BLOCKS + DUMP_GROUP + 1u;  // 49 blocks = 784 st
 // LDS and 16 waves fit a CU.
 //   nb <= 17 : R = 0,                Ld = nb - 1
 //   else     : R = min(32, nb - 17), Ld = nb - R - 1  (>= 16 = one dump group)
-// Frames longer than a segment are decoded in segments: a forward pass without history saves the
-// path metrics at every segment boundary (512 B), then the segments are recomputed with history
-// and traced back last to first.
+// Frames longer than a segment take vit_pk_long_kernel below (blocks beyond the last 17 go through HBM).
 __host__ __device__ inline u32 pk_reg_blocks(u32 nb) {
     if (nb <= DUMP_GROUP + 1u) return 0;
     const u32 r = nb - (DUMP_GROUP + 1u);
@@ -279,30 +293,20 @@ __host__ __device__ inline u32 pk_scratch_words(u32 maxfb) {
 }
 struct PkLayout {
     u32 dec_bytes;  // tab starts here
-    u32 cp_off;     // checkpoints (nseg - 1) x 512 B, 0 if none
     u32 img_off;    // output bit image
     u32 total;
     u32 maxfb;      // the framebits this layout was sized for
 };
-__host__ __device__ inline PkLayout pk_layout(u32 maxfb) {
-    const u32 nblk = (maxfb + VIT_TAIL + 15u) >> 4;
-    const u32 nseg = (nblk + SEG_BLOCKS - 1u) / SEG_BLOCKS;
-    const u32 nb = nblk < SEG_BLOCKS ? nblk : SEG_BLOCKS;
+__host__ __device__ inline PkLayout pk_layout(u32 maxfb) {  // single-segment kernel (nblk <= 49)
+    const u32 nb = (maxfb + VIT_TAIL + 15u) >> 4;
     PkLayout l;
     l.maxfb = maxfb;
     l.dec_bytes = (nb - pk_reg_blocks(nb) - 1u) * DEC_BLOCK;
     const u32 scratch = 64u * 4u * pk_scratch_words(maxfb), img = 16u * pk_img_stride(maxfb);
-    if (nseg == 1) {  // the image can live in the dead table region too
-        u32 tabregion = DEC_BLOCK + scratch + img;
-        tabregion = tabregion > (u32)TAB_BYTES ? ((tabregion + 15u) & ~15u) : (u32)TAB_BYTES;
-        l.cp_off = 0;
-        l.img_off = l.dec_bytes + DEC_BLOCK + scratch;
-        l.total = l.dec_bytes + tabregion;
-    } else {  // table stays live across segments: checkpoints and image get their own space
-        l.cp_off = l.dec_bytes + TAB_BYTES;
-        l.img_off = l.cp_off + (nseg - 1u) * 512u;
-        l.total = l.img_off + ((img + 15u) & ~15u);
-    }
+    u32 tabregion = DEC_BLOCK + scratch + img;  // the image lives in the dead table region too
+    tabregion = tabregion > (u32)TAB_BYTES ? ((tabregion + 15u) & ~15u) : (u32)TAB_BYTES;
+    l.img_off = l.dec_bytes + DEC_BLOCK + scratch;
+    l.total = l.dec_bytes + tabregion;
     return l;
 }
 
@@ -441,21 +445,31 @@ u32 traceback_part(const char* dec, u32* scratch, u32* img, u32 fstride, u32 lan
     return __shfl(P_out, (int)(fi * 16u));  // block 0 of the frame ends at step ts
 }
 
-// MULTI = false: every frame fits one segment (the FIC fast path; the phase loop folds away).
-#ifndef VIT_MULTI_WAVES
-#define VIT_MULTI_WAVES 3  /* 132 VGPRs, no spills */
-#endif
-template <bool MULTI>
-__global__ __launch_bounds__(64, MULTI ? VIT_MULTI_WAVES : 4) void vit_pk_kernel(const uint8_t* __restrict__ sym, uint8_t* __restrict__ out,
-                                                    const vit_frame_desc* __restrict__ desc,
-                                                    u32 framebits_uniform, long long nframes, PkLayout lay) {
+// Single-segment kernel: every frame of the launch fits 49 blocks (framebits <= 778; the FIC fast path).
+template <bool SYM32>
+__global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict__ sym, uint8_t* __restrict__ out,
+                                                        const vit_frame_desc* __restrict__ desc, u32 framebits_uniform,
+                                                        long long nframes, PkLayout lay) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* dec = lds;                  // [block - R][lane] -> (acc0, acc1); the last block spills into tab
-    char* tab = lds + lay.dec_bytes;  // [tau][pair][c] -> M; after a segment's ACS: last block, scratch
-    uint2* cp = reinterpret_cast<uint2*>(lds + lay.cp_off);  // (A,B) at the start of segments 1..nseg-1
-    u32* img = reinterpret_cast<u32*>(lds + lay.img_off);    // output bit image, 4 frames
+    char* tab = lds + lay.dec_bytes;  // [tau][pair][c] -> M; after the ACS: last block, scratch, image
+    u32* img = reinterpret_cast<u32*>(lds + lay.img_off);  // output bit image, 4 frames
     const u32 lane = threadIdx.x;
     const long long f0 = (long long)blockIdx.x * 4;
+#if VIT_PRIO
+    // Stagger the waves that share a SIMD: different issue priorities make them drift apart, so the
+    // latency-bound traceback of one overlaps the ACS of the others instead of all four hitting it together.
+    {
+        u32 hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        switch (hwid & 3u) {  // wave slot within the SIMD
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+    }
+#endif
 
     // ---- per-frame parameters (wave-uniform loads) ----
     u32 fbits[4];
@@ -483,12 +497,11 @@ __global__ __launch_bounds__(64, MULTI ? VIT_MULTI_WAVES : 4) void vit_pk_kernel
         maxfb = fbits[k] > maxfb ? fbits[k] : maxfb;
     }
     if (maxfb == 0) return;
-    const u32 nblk = (maxfb + VIT_TAIL + 15u) >> 4;
-    const u32 nseg = MULTI ? (nblk + SEG_BLOCKS - 1u) / SEG_BLOCKS : 1u;
+    const u32 nb = (maxfb + VIT_TAIL + 15u) >> 4, R = pk_reg_blocks(nb);
     const u32 fstride = pk_img_stride(maxfb);  // image dwords per frame (+ slack for the shifted spill)
     const u32 T_max = maxfb + VIT_TAIL;
 
-    // ---- ACS-phase lane constants ----
+    // ---- ACS lane constants ----
     const u32 l5 = lane & 31u, pair = lane >> 5;
     Lanes L;
 #pragma unroll
@@ -505,8 +518,9 @@ __global__ __launch_bounds__(64, MULTI ? VIT_MULTI_WAVES : 4) void vit_pk_kernel
     const u32 tau = lane >> 1, pp = lane & 1u;
     const u32 a_fb = pp ? fbits[2] : fbits[0], b_fb = pp ? fbits[3] : fbits[1];
     const u32 a_T = a_fb ? a_fb + VIT_TAIL : 0u, b_T = b_fb ? b_fb + VIT_TAIL : 0u;
-    const u32* a_sym = reinterpret_cast<const u32*>(sym + (pp ? soff[2] : soff[0]));
-    const u32* b_sym = reinterpret_cast<const u32*>(sym + (pp ? soff[3] : soff[1]));
+    constexpr size_t SB = SYM32 ? 4 : 1;  // bytes per soft symbol in memory
+    const uint8_t* a_sym = sym + SB * (pp ? soff[2] : soff[0]);
+    const uint8_t* b_sym = sym + SB * (pp ? soff[3] : soff[1]);
     u32 sel[4];
     {
         const u32 hb = (tau & 1u) ? 0x0C000C00u : 0x0D000D00u;  // even step: 0xFF high bytes (= +0xFF00)
@@ -515,98 +529,59 @@ __global__ __launch_bounds__(64, MULTI ? VIT_MULTI_WAVES : 4) void vit_pk_kernel
     }
     u32 A = l5 == 0 ? 0u : 0x003F003Fu, B = 0x003F003Fu;  // const.asm:19-25 (0-based, step 0 is even)
     u32 acc0 = 0, acc1 = 0;
-    u32 P_next = P_ZERO;  // per frame: traceback position at the start of the segment above
+    v32u r0, r1;  // register-resident decisions of blocks [0,R)
 
-    // Phases: forward over segments 0..nseg-1 (history only in the last one), then the earlier
-    // segments again, last to first, recomputed from their checkpoints with history.
-    const u32 nphase = 2u * nseg - 1u;
-    auto phase = [&](const u32 ph) {
-        v32u r0, r1;  // register-resident decisions of this segment's blocks [0,R); dead at the end of the phase
-        const bool fwd = ph < nseg;
-        const u32 seg = fwd ? ph : 2u * nseg - 2u - ph;
-        const bool hist = !fwd || seg + 1u == nseg;
-        const u32 b0 = seg * SEG_BLOCKS, b1 = (b0 + SEG_BLOCKS < nblk) ? b0 + SEG_BLOCKS : nblk;
-        const u32 nb = b1 - b0, R = pk_reg_blocks(nb);
-        if (!fwd) {
-            if (seg) {
-                const uint2 c = cp[(seg - 1u) * 64u + lane];
-                A = c.x;
-                B = c.y;
+    // ---- ACS over the blocks ----
+    {
+        u32 sa = tau < a_T ? load_step<SYM32>(a_sym, tau) : 0u, sb = tau < b_T ? load_step<SYM32>(b_sym, tau) : 0u;
+        u32 v = 0;
+        for (u32 rb = 0; rb < nb; rb++) {
+            if ((rb & 1u) == 0) {
+                __syncthreads();  // every lane is done with the previous table
+                prepass(sa, sb, tab, lane, sel);
+                const u32 tn = (rb + 2u) * 16u + tau;
+                sa = tn < a_T ? load_step<SYM32>(a_sym, tn) : 0u;  // prefetch the next 32 steps' symbols
+                sb = tn < b_T ? load_step<SYM32>(b_sym, tn) : 0u;
+                __syncthreads();
+            }
+            steps16<true>(v, A, B, acc0, acc1, tab + (rb & 1u) * 1024u, L, lane, C);
+            if (rb < R) {
+                r0[rb] = acc0;  // s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off
+                r1[rb] = acc1;
             } else {
-                A = (lane & 31u) == 0 ? 0u : 0x003F003Fu;
-                B = 0x003F003Fu;
+                if (rb + 1u == nb) __syncthreads();  // the last block lands on the table: all reads done first
+                *reinterpret_cast<uint2*>(dec + (rb - R) * DEC_BLOCK + lane * 8) = make_uint2(acc0, acc1);
             }
+            v = v == 4 ? 0 : v + 1;
         }
-        // ---- ACS over the segment's blocks ----
-        {
-            const u32 t0 = b0 * 16u + tau;
-            u32 sa = t0 < a_T ? a_sym[t0] : 0u, sb = t0 < b_T ? b_sym[t0] : 0u;
-            u32 v = b0 % 5u;
-            for (u32 rb = 0; rb < nb; rb++) {
-                if ((rb & 1u) == 0) {
-                    __syncthreads();  // every lane is done with the previous table / scratch
-                    prepass(sa, sb, tab, lane, sel);
-                    const u32 tn = (b0 + rb + 2u) * 16u + tau;
-                    sa = tn < a_T ? a_sym[tn] : 0u;  // prefetch the next 32 steps' symbols
-                    sb = tn < b_T ? b_sym[tn] : 0u;
-                    __syncthreads();
-                }
-                const char* th = tab + (rb & 1u) * 1024u;
-                if (hist) {
-                    steps16<true>(v, A, B, acc0, acc1, th, L, lane, C);
-                    if (rb < R) {
-                        r0[rb] = acc0;  // s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off
-                        r1[rb] = acc1;
-                    } else {
-                        if (rb + 1u == nb) __syncthreads();  // the last block lands on the table: all reads done first
-                        *reinterpret_cast<uint2*>(dec + (rb - R) * DEC_BLOCK + lane * 8) = make_uint2(acc0, acc1);
-                    }
-                } else {
-                    steps16<false>(v, A, B, acc0, acc1, th, L, lane, C);
-                }
-                v = v == 4 ? 0 : v + 1;
-            }
-        }
-        if (fwd && seg + 1u < nseg) cp[seg * 64u + lane] = make_uint2(A, B);
-        if (!hist) return;
-        __syncthreads();
-        if (fwd)  // first traceback of this group: clear the image (it may alias the table region)
-            for (u32 i = lane; i < 4u * fstride; i += 64u) img[i] = 0;
+    }
+    __syncthreads();
+    for (u32 i = lane; i < 4u * fstride; i += 64u) img[i] = 0;  // the image aliases the dead table region
 
-        // ---- traceback of the segment, last part first: lane = (frame fi, block q) ----
-        const u32 fi = lane >> 4;
-        const u32 t_fb = fi == 0 ? fbits[0] : fi == 1 ? fbits[1] : fi == 2 ? fbits[2] : fbits[3];
-        const u32 t_T = t_fb ? t_fb + VIT_TAIL : 0u;  // steps of this lane's frame
-        u32* scratch = reinterpret_cast<u32*>(tab + DEC_BLOCK) + lane * pk_scratch_words(maxfb);  // traceback bit words
-        const u32 seg_end = b1 * 16u;  // steps >= seg_end are done; frames reaching beyond continue from P_next
-        const u32 te_seg = t_T < seg_end ? t_T : seg_end, te_seg_max = T_max < seg_end ? T_max : seg_end;
-        const u32 P_top_seg = t_T > seg_end ? P_next : P_ZERO;
-        // LDS-resident blocks [b0+R, b1)
-        const u32 t_lo = (b0 + R) * 16u;
-        u32 P_part = traceback_part(dec, scratch, img, fstride, lane, t_lo > VIT_TAIL ? t_lo : VIT_TAIL, te_seg,
-                                    te_seg_max, b0 + R, P_top_seg);
-        // register-resident blocks, 16 at a time from the top
-        for (u32 g1 = R; g1 > 0;) {
-            const u32 g0 = g1 > DUMP_GROUP ? g1 - DUMP_GROUP : 0u;  // group = segment blocks [g0, g1)
-            __syncthreads();
+    // ---- traceback, last part first: lane = (frame fi, block q) ----
+    const u32 fi = lane >> 4;
+    const u32 t_fb = fi == 0 ? fbits[0] : fi == 1 ? fbits[1] : fi == 2 ? fbits[2] : fbits[3];
+    const u32 t_T = t_fb ? t_fb + VIT_TAIL : 0u;  // steps of this lane's frame
+    u32* scratch = reinterpret_cast<u32*>(tab + DEC_BLOCK) + lane * pk_scratch_words(maxfb);  // traceback bit words
+    // LDS-resident blocks [R, nb)
+    const u32 t_lo = R * 16u;
+    u32 P_part = traceback_part(dec, scratch, img, fstride, lane, t_lo > VIT_TAIL ? t_lo : VIT_TAIL, t_T, T_max, R,
+                                P_ZERO);
+    // register-resident blocks, 16 at a time from the top
+    for (u32 g1 = R; g1 > 0;) {
+        const u32 g0 = g1 > DUMP_GROUP ? g1 - DUMP_GROUP : 0u;  // group = blocks [g0, g1)
+        __syncthreads();
 #pragma unroll
-            for (u32 b = 0; b < VREG_BLOCKS; b++)
-                if (b >= g0 && b < g1)
-                    *reinterpret_cast<uint2*>(dec + (b - g0) * DEC_BLOCK + lane * 8) = make_uint2(r0[b], r1[b]);
-            __syncthreads();
-            const u32 tsg = (b0 + g0) ? (b0 + g0) * 16u : VIT_TAIL, tend = (b0 + g1) * 16u;
-            const u32 te = t_T < tend ? t_T : tend, te_max = T_max < tend ? T_max : tend;
-            // a frame that reaches beyond this group continues from the position the later part ended in
-            const u32 P_top = t_T > tend ? P_part : P_ZERO;
-            P_part = traceback_part(dec, scratch, img, fstride, lane, tsg, te, te_max, b0 + g0, P_top);
-            g1 = g0;
-        }
-        P_next = P_part;
-    };
-    if constexpr (MULTI) {
-        for (u32 ph = 0; ph < nphase; ph++) phase(ph);
-    } else {
-        phase(0);
+        for (u32 b = 0; b < VREG_BLOCKS; b++)
+            if (b >= g0 && b < g1)
+                *reinterpret_cast<uint2*>(dec + (b - g0) * DEC_BLOCK + lane * 8) = make_uint2(r0[b], r1[b]);
+        __syncthreads();
+        const u32 tsg = g0 ? g0 * 16u : VIT_TAIL, tend = g1 * 16u;
+        const u32 te = t_T < tend ? t_T : tend, te_max = T_max < tend ? T_max : tend;
+        // a frame that reaches beyond this group continues from the position the later part ended in
+        const u32 P_top = t_T > tend ? P_part : P_ZERO;
+        P_part = traceback_part(dec, scratch, img, fstride, lane, tsg, te, te_max, g0, P_top);
+        g1 = g0;
     }
     __syncthreads();
 
@@ -627,7 +602,6 @@ __global__ __launch_bounds__(64, MULTI ? VIT_MULTI_WAVES : 4) void vit_pk_kernel
     }
 }
 
-
 // ---- frames longer than one segment: decisions beyond the last 17 blocks go through HBM ---------
 // (replaces the checkpoint + recompute scheme: one forward pass with history; HBM has >90 % headroom
 // on this VALU-bound path, so 8 B/step of spill each way is cheaper than 0.7 extra ACS passes.)
@@ -646,12 +620,12 @@ __host__ __device__ inline PkLayout pk_layout_long(u32 maxfb) {
     const u32 scratch = 64u * 4u * pk_scratch_words(maxfb), img = 16u * pk_img_stride(maxfb);
     u32 tabregion = DEC_BLOCK + scratch + img;
     tabregion = tabregion > (u32)TAB_BYTES ? ((tabregion + 15u) & ~15u) : (u32)TAB_BYTES;
-    l.cp_off = 0;
     l.img_off = l.dec_bytes + DEC_BLOCK + scratch;
     l.total = l.dec_bytes + tabregion;
     return l;
 }
 
+template <bool SYM32>
 __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __restrict__ sym, uint8_t* __restrict__ out,
                                                              const vit_frame_desc* __restrict__ desc,
                                                              u32 framebits_uniform, long long nframes, PkLayout lay,
@@ -720,22 +694,23 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
         const u32 T_max = maxfb + VIT_TAIL;
         const u32 a_fb = pp ? fbits[2] : fbits[0], b_fb = pp ? fbits[3] : fbits[1];
         const u32 a_T = a_fb ? a_fb + VIT_TAIL : 0u, b_T = b_fb ? b_fb + VIT_TAIL : 0u;
-        const u32* a_sym = reinterpret_cast<const u32*>(sym + (pp ? soff[2] : soff[0]));
-        const u32* b_sym = reinterpret_cast<const u32*>(sym + (pp ? soff[3] : soff[1]));
+        constexpr size_t SB = SYM32 ? 4 : 1;  // bytes per soft symbol in memory
+        const uint8_t* a_sym = sym + SB * (pp ? soff[2] : soff[0]);
+        const uint8_t* b_sym = sym + SB * (pp ? soff[3] : soff[1]);
 
         // ---- forward pass: ACS with history over all blocks ----
         u32 A = l5 == 0 ? 0u : 0x003F003Fu, B = 0x003F003Fu;
         u32 acc0 = 0, acc1 = 0;
         {
-            u32 sa = tau < a_T ? a_sym[tau] : 0u, sb = tau < b_T ? b_sym[tau] : 0u;
+            u32 sa = tau < a_T ? load_step<SYM32>(a_sym, tau) : 0u, sb = tau < b_T ? load_step<SYM32>(b_sym, tau) : 0u;
             u32 v = 0;
             for (u32 rb = 0; rb < nblk; rb++) {
                 if ((rb & 1u) == 0) {
                     __syncthreads();
                     prepass(sa, sb, tab, lane, sel);
                     const u32 tn = (rb + 2u) * 16u + tau;
-                    sa = tn < a_T ? a_sym[tn] : 0u;
-                    sb = tn < b_T ? b_sym[tn] : 0u;
+                    sa = tn < a_T ? load_step<SYM32>(a_sym, tn) : 0u;
+                    sb = tn < b_T ? load_step<SYM32>(b_sym, tn) : 0u;
                     __syncthreads();
                 }
                 steps16<true>(v, A, B, acc0, acc1, tab + (rb & 1u) * 1024u, L, lane, C);
@@ -830,18 +805,22 @@ bool sort_enabled() {
     return on;
 }
 
-hipError_t vit_launch_pk(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_desc* d_desc, uint32_t framebits,
-                         uint32_t max_framebits, int64_t nframes, hipStream_t stream) {
+hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, const vit_frame_desc* d_desc,
+                         uint32_t framebits, uint32_t max_framebits, int64_t nframes, hipStream_t stream) {
+    const uint8_t* d_sym = static_cast<const uint8_t*>(d_symbols);
+    if (sym32 && (reinterpret_cast<uintptr_t>(d_symbols) & 15u)) return hipErrorInvalidValue;  // uint4 loads
     if (nframes <= 0) return hipSuccess;
     if (!vit_pk_supported(max_framebits)) return hipErrorInvalidValue;
     static std::once_flag attr_once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(attr_once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(vit_pk_kernel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (attr_err == hipSuccess)
-            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(vit_pk_long_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const void* ks[4] = {reinterpret_cast<const void*>(vit_pk_kernel<false>),
+                             reinterpret_cast<const void*>(vit_pk_kernel<true>),
+                             reinterpret_cast<const void*>(vit_pk_long_kernel<false>),
+                             reinterpret_cast<const void*>(vit_pk_long_kernel<true>)};
+        for (const void* k : ks)
+            if (attr_err == hipSuccess)
+                attr_err = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     if (attr_err != hipSuccess) return attr_err;
     const long long groups = (nframes + 3) / 4;
@@ -851,8 +830,12 @@ hipError_t vit_launch_pk(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_d
     const bool sort = d_desc != nullptr && nframes >= SORT_MIN_FRAMES && sort_enabled();
     if (!is_long && !sort) {
         const PkLayout lay = pk_layout(max_framebits);
-        hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)groups), dim3(64), lay.total, stream, d_sym, d_out,
-                           d_desc, framebits, (long long)nframes, lay);
+        if (sym32)
+            hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)groups), dim3(64), lay.total, stream, d_sym, d_out,
+                               d_desc, framebits, (long long)nframes, lay);
+        else
+            hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)groups), dim3(64), lay.total, stream, d_sym, d_out,
+                               d_desc, framebits, (long long)nframes, lay);
         return hipGetLastError();
     }
     const PkLayout lay = is_long ? pk_layout_long(max_framebits) : pk_layout(max_framebits);
@@ -896,9 +879,17 @@ hipError_t vit_launch_pk(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_d
     }
     if (is_long) {
         if ((e = hipMemsetAsync(base, 0, 256, stream)) != hipSuccess) return e;
-        hipLaunchKernelGGL(vit_pk_long_kernel, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out, d_desc,
-                           framebits, (long long)nframes, lay, reinterpret_cast<uint2*>(base + SCRATCH_HDR + desc_bytes),
-                           spill_blocks, reinterpret_cast<unsigned*>(base), (u32)groups);
+        uint2* spill = reinterpret_cast<uint2*>(base + SCRATCH_HDR + desc_bytes);
+        unsigned* counter = reinterpret_cast<unsigned*>(base);
+        if (sym32)
+            hipLaunchKernelGGL(vit_pk_long_kernel<true>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
+                               d_desc, framebits, (long long)nframes, lay, spill, spill_blocks, counter, (u32)groups);
+        else
+            hipLaunchKernelGGL(vit_pk_long_kernel<false>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
+                               d_desc, framebits, (long long)nframes, lay, spill, spill_blocks, counter, (u32)groups);
+    } else if (sym32) {
+        hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)groups), dim3(64), lay.total, stream, d_sym, d_out,
+                           d_desc, framebits, (long long)nframes, lay);
     } else {
         hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)groups), dim3(64), lay.total, stream, d_sym, d_out,
                            d_desc, framebits, (long long)nframes, lay);

@@ -142,3 +142,16 @@ want = O.decode_batch(768, stream[:256].cpu().numpy(), nthreads=16)
 ok = bool(np.array_equal(out[:256].cpu().numpy(), want)) and bool(torch.equal(out[:chunk * 4], out[-chunk * 4:]))
 print(json.dumps({"case": "config4 at N=1: 4M FIC frames resident (13.0 GB), one launch", "frames": n_total,
                   "ms": round(ms, 2), "Mbit_s": round(n_total * 768 / ms / 1e3, 1), "parity_sample_ok": ok}), flush=True)
+
+# ---- ingest: 65536 FIC frames still in the reference ABI's u32-per-symbol format, resident in HBM ----
+n = 65536
+sym8 = make_frames(n, 768, seed=21, device=dev)
+sym32 = sym8.to(torch.int32)
+out = torch.zeros((n, 96), dtype=torch.uint8, device=dev)
+ms32 = timeit(lambda: V.decode_batch_dev_u32(sym32, out, 768, n))
+got32 = out.clone()
+ms8 = timeit(lambda: V.decode_batch_dev(sym8, out, 768, n))
+print(json.dumps({"case": "u32 ingest (reference ABI format in HBM), 65536 FIC frames", "ms_u32": round(ms32, 4),
+                  "ms_u8": round(ms8, 4), "Mbit_s_u32": round(n * 768 / ms32 / 1e3, 1),
+                  "abi_format_GB_s": round(n * (4 * 3096 + 96) / ms32 / 1e6, 1),
+                  "same_output": bool(torch.equal(got32, out))}), flush=True)

@@ -101,22 +101,29 @@ typedef struct vit_frame_desc {
  * NULL = default stream) without synchronising. */
 int vit_decode_batch_dev(const uint8_t *d_symbols_u8, uint8_t *d_decoded,
                          uint32_t framebits, int64_t nframes, void *stream);
-/* Same, symbols still in the reference ABI format (u32 per symbol); the
- * u32->u8 narrowing runs on the device into an internal scratch buffer. */
+/* Same, symbols still in the reference ABI format (u32 per symbol, low byte
+ * used).  With a 16-byte aligned buffer and framebits % 8 == 0 the decoder
+ * reads them in place (narrowing fused into the kernel); otherwise they are
+ * narrowed on the device into an internal scratch buffer first. */
 int vit_decode_batch_dev_u32(const uint32_t *d_symbols_u32, uint8_t *d_decoded,
                              uint32_t framebits, int64_t nframes, void *stream);
 /* Variable-length batch; d_desc is a DEVICE array of nframes descriptors,
  * max_framebits the largest framebits in it (host-known).  A descriptor whose
  * framebits exceeds max_framebits is skipped (its output bytes stay untouched);
  * if any framebits is not a multiple of 8 the whole batch must go through
- * vit_set_kernel(1), the wave-per-frame kernel. */
+ * vit_set_kernel(1), the wave-per-frame kernel.  Tables of 16 or more frames
+ * are length-sorted on the device into an internal copy first (longest frame
+ * first: a wavefront decodes four consecutive descriptors and runs as long as
+ * the longest); d_desc itself is never modified and the order changes no
+ * output byte.  Frames longer than 778 bits use a per-thread HBM scratch
+ * buffer for their decision history (grown on demand). */
 int vit_decode_varlen_dev(const uint8_t *d_symbols_u8, uint8_t *d_decoded,
                           const vit_frame_desc *d_desc, int64_t nframes,
                           uint32_t max_framebits, void *stream);
 /* Host helper: reorder a HOST array of descriptors by framebits (longest first, stable) before
- * uploading it.  A wavefront decodes four consecutive descriptors and runs as long as the longest
- * of them, so a length-sorted table is what a mixed batch wants (BASELINE config 3: +40 %);
- * every descriptor carries its own offsets, so the order does not change any output byte. */
+ * uploading it.  Optional since the device-side sort above; kept for callers that build tables of
+ * fewer than 16 frames or want a deterministic order.  Every descriptor carries its own offsets,
+ * so the order does not change any output byte. */
 void vit_sort_descs(vit_frame_desc *h_desc, int64_t nframes);
 /* u32 -> u8 narrowing of nsym symbols on the device (ingest stage). */
 int vit_pack_symbols_dev(const uint32_t *d_symbols_u32, uint8_t *d_symbols_u8,

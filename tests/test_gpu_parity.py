@@ -261,6 +261,42 @@ def test_varlen_device_sort_mixed_and_invalid(V, O, torch_cuda):
     assert np.array_equal(d_out2.cpu().numpy(), want2)
 
 
+def test_long_frames_from_threads_and_streams(V, O, torch_cuda):
+    """the long-frame kernel's spill/sort scratch is per calling thread and its reuse is ordered by an
+    event: two threads, each alternating between two streams with different frame lengths, back to back"""
+    import threading
+    torch = torch_cuda
+    cases = [(3072, 37), (1536, 61), (9216, 9), (2304, 33)]
+    data = []
+    for fb, n in cases:
+        sym = _mixed_input(O, n, fb, seed=fb)
+        data.append((fb, n, torch.from_numpy(sym).cuda(), O.decode_batch(fb, sym, nthreads=8)))
+    errs = []
+
+    def work(tid):
+        try:
+            streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            outs = []
+            for rep in range(6):
+                fb, n, d_sym, want = data[(tid + rep) % len(data)]
+                st = streams[rep & 1]
+                with torch.cuda.stream(st):
+                    d_out = torch.zeros((n, fb // 8), dtype=torch.uint8, device="cuda")
+                    V.decode_batch_dev(d_sym, d_out, fb, n, stream=st.cuda_stream)
+                outs.append((d_out, want, fb))
+            torch.cuda.synchronize()
+            for d_out, want, fb in outs:
+                if not np.array_equal(d_out.cpu().numpy(), want):
+                    errs.append((tid, fb))
+        except Exception as e:  # noqa: BLE001
+            errs.append((tid, repr(e)))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+
+
 def test_varlen_descriptor_longer_than_declared_is_skipped(V, O, torch_cuda):
     torch = torch_cuda
     fbs = [768, 1536, 768, 768, 288]

@@ -14,7 +14,9 @@ p = np.empty((base_n, 120, rsdims), np.uint8)
 for s in range(base_n):
     for j in range(rsdims):
         cw = O.rs_encode(rng.integers(0, 256, 110, dtype=np.uint8))
-        ne = 0 if mode == "clean" else int(rng.choice([0, 0, 0, 0, 1, 2, 3, 5, 6]))
+        # clean: no errors; light: one symbol error in 6 % of the columns (what Eb/N0 = 3 dB leaves behind);
+        # mixed: errors in 5/9 of the columns incl. uncorrectable ones
+        ne = 0 if mode == "clean" else (int(rng.random() < 0.06) if mode == "light" else int(rng.choice([0, 0, 0, 0, 1, 2, 3, 5, 6])))
         pos = rng.choice(120, ne, replace=False); cw[pos] ^= rng.integers(1, 256, ne, dtype=np.uint8)
         p[s, :, j] = cw
 p = p.reshape(base_n, -1)

@@ -23,3 +23,30 @@ for fb, n in ((768, 262144), (288, 131072), (1536, 65536), (3072, 32768), (6912,
         total += n; bad += nb
         print(json.dumps({"framebits": fb, "kind": kind, "frames": n, "differing": nb}), flush=True)
 print(json.dumps({"total_frames": total, "differing": bad, "seconds": round(time.time() - t0, 1)}))
+
+# ---- RS(120,110): random superframes with 0..8 symbol errors per column (clean, corrected, uncorrectable,
+# miscorrected towards the virtual padding), GPU vs oracle: return values and every output byte ----
+t0 = time.time()
+rs_total = rs_bad = 0
+for rsdims, nsf in ((24, 6000), (12, 6000), (5, 4000), (1, 3000), (37, 2000), (256, 300), (300, 200)):
+    rng = np.random.default_rng(1000 + rsdims)
+    msg = rng.integers(0, 256, (nsf * rsdims, 110), dtype=np.uint8)
+    cws = np.stack([O.rs_encode(m) for m in msg[:512]])            # 512 distinct codewords, reused
+    cw = cws[rng.integers(0, 512, nsf * rsdims)]
+    # three regimes by superframe: correctable only / heavy incl. uncorrectable / mostly clean with rare 6..8
+    regime = (np.arange(nsf * rsdims) // rsdims) % 3
+    ne = np.where(regime == 0, rng.choice([0, 0, 0, 0, 1, 1, 2, 3, 4, 5], nsf * rsdims),
+                  np.where(regime == 1, rng.choice([0, 0, 0, 1, 1, 2, 3, 4, 5, 6, 7, 8], nsf * rsdims),
+                           rng.choice([0] * 60 + [1, 1, 2, 6, 7, 8], nsf * rsdims)))
+    for i in np.nonzero(ne)[0]:
+        pos = rng.choice(120, ne[i], replace=False)
+        cw[i, pos] ^= rng.integers(1, 256, ne[i], dtype=np.uint8)
+    p = cw.reshape(nsf, rsdims, 120).transpose(0, 2, 1).reshape(nsf, 120 * rsdims).copy()
+    init = rng.integers(0, 256, (nsf, 110 * rsdims), dtype=np.uint8)
+    ret_ref, out_ref = O.rs_check_batch(p, rsdims, out_init=init)
+    d_out = torch.from_numpy(init.copy()).to(dev); d_ret = torch.zeros(nsf, dtype=torch.int32, device=dev)
+    V.rs_batch_dev(torch.from_numpy(p).to(dev), d_out, d_ret, rsdims, nsf); torch.cuda.synchronize()
+    nb = int((d_ret.cpu().numpy() != ret_ref).sum()) + int((d_out.cpu().numpy() != out_ref).any(axis=1).sum())
+    rs_total += nsf; rs_bad += nb
+    print(json.dumps({"rsdims": rsdims, "superframes": nsf, "failed_superframes": int((ret_ref < 0).sum()), "differing": nb}), flush=True)
+print(json.dumps({"rs_superframes": rs_total, "rs_differing": rs_bad, "seconds": round(time.time() - t0, 1)}))

@@ -3,9 +3,16 @@
 //
 // One lane decodes one column (codeword); a 256-thread workgroup takes whole
 // superframes so the reference's "stop at the first uncorrectable column"
-// rule (rschecksf.cpp:80-88) is a workgroup-local min-reduction.  Codeword
-// bytes live in LDS transposed ([row][lane]) so the strided column gather of
-// rschecksf.cpp:75-76 is a coalesced byte load across lanes.
+// rule (rschecksf.cpp:80-88) is a workgroup-local min-reduction.
+//
+// rs_kernel (RSDims <= 256, the DAB+ range): the workgroup's superframes are copied HBM -> LDS
+// -> HBM with 16-byte accesses in their natural layout p[j + k*RSDims] (rschecksf.cpp:75-76: lanes
+// of one superframe read consecutive bytes of a row, so the column gather needs no transposition).
+// The 1190 multiply-adds of the syndrome loop (rschecksf.cpp:210-219) are replaced by the remainder
+// of the codeword modulo the generator polynomial: one 16-byte LDS lookup per data byte
+// (x -> x*g_0..x*g_9) instead of nine byte lookups; a zero remainder is a clean codeword, otherwise
+// the ten syndromes are the remainder evaluated at alpha^i (same field elements as the reference's
+// Horner sums, since g(alpha^i) = 0).  rs_kernel_wide keeps the transposed-LDS form for RSDims > 256.
 //
 // Replaces, from scratch: RScheckSuperframe (rschecksf.cpp:65-93), DECODE_RS
 // (:199-377), Mod255 (:50-52) and CreateLookupTables (dllmain.cpp:124-146).
@@ -40,31 +47,74 @@ constexpr GfTables make_tables() {
 }
 __constant__ GfTables g_gf = make_tables();
 
+// G[x] = (x*g_0, ..., x*g_9) packed little-endian into 16 bytes, g(x) = prod_{i=0..9}(x + alpha^i)
+// (monic, degree 10): the feedback table of the remainder LFSR.
+struct GenTable {
+    uint32_t w[256 * 4];
+};
+constexpr GenTable make_gen_table() {
+    const GfTables t = make_tables();
+    uint8_t g[NROOTS + 1] = {1};
+    int deg = 0;
+    for (int i = 0; i < NROOTS; i++) {  // multiply by (x + alpha^i)
+        const uint8_t root = t.ato[i];
+        uint8_t ng[NROOTS + 1] = {};
+        for (int j = 0; j <= deg; j++) {
+            ng[j + 1] ^= g[j];
+            if (g[j]) ng[j] ^= t.ato[t.iof[g[j]] + t.iof[root]];
+        }
+        deg++;
+        for (int j = 0; j <= deg; j++) g[j] = ng[j];
+    }
+    GenTable G{};
+    for (int x = 1; x < 256; x++)
+        for (int j = 0; j < NROOTS; j++) {
+            const uint32_t prod = g[j] ? t.ato[t.iof[x] + t.iof[g[j]]] : 0u;
+            G.w[x * 4 + j / 4] |= prod << (8 * (j % 4));
+        }
+    return G;
+}
+__constant__ GenTable g_gen = make_gen_table();
+
 __device__ __forceinline__ uint32_t mod255(uint32_t x) { return (x * 0x1010102u) >> 24; }
 
-// Decode the codeword stored at col[k * RS_THREADS], k = 0..119 (LDS, transposed).
-// Returns root count, 0 when clean, -1 when uncorrectable; patches in place.
+// Chien search over i = 1..255 for a wave whose locator polynomials all have degree <= D
+// (rschecksf.cpp:299-320): the reference advances the logs b[j] += j and sums alpha_to[b[j]]; here the
+// same terms lambda_j * alpha^(j*i) are kept in polynomial form and advanced with the product tables
+// (one LDS byte per term, no mod-255 arithmetic).  Terms above D are zero in every lane.
+template <int D>
+__device__ __forceinline__ void chien(uint32_t (&c)[NROOTS + 1], uint32_t (&root)[NROOTS], int& count, int deg_lambda,
+                                      const uint8_t* __restrict__ mulp) {
+    bool searching = true;
+    for (int i = 1; i <= NN; i++) {
+        if (searching) {
+            uint32_t q = 1;  // lambda[0] is always 1
+#pragma unroll
+            for (int j = D; j > 0; j--) {
+                c[j] = mulp[j * 256 + c[j]];
+                q ^= c[j];
+            }
+            if (q == 0) {
+#pragma unroll
+                for (int k = 0; k < D; k++)
+                    if (count == k) root[k] = (uint32_t)i;
+                if (++count == deg_lambda) searching = false;
+            }
+        }
+        if (!__any(searching)) break;
+    }
+}
+
+// Everything after the syndromes: s[] = the ten syndromes in polynomial form, not all zero.
+// Codeword byte k is col[k * stride].  Returns root count or -1 when uncorrectable; patches in place.
 // Every small polynomial array is indexed with compile-time constants only (loops fully
 // unrolled, data-dependent bounds turned into predicates): dynamically indexed register arrays
 // cost a v_cndmask chain per access on this target and made the error path ~8x slower.
-__device__ int decode_rs(uint8_t* col, const uint8_t* __restrict__ ato, const uint8_t* __restrict__ iof,
-                         const uint8_t* __restrict__ mulp) {
-    uint32_t s[NROOTS];
-    const uint32_t d0 = col[0];
-#pragma unroll
-    for (int i = 0; i < NROOTS; i++) s[i] = d0;
-    for (int j = 1; j < NCW; j++) {  // syndromes, Horner (rschecksf.cpp:212-219)
-        const uint32_t d = col[j * RS_THREADS];
-        // s*alpha^i from a per-root product table (mulp[i][x] = x ? alpha_to[index_of[x]+i] : 0):
-        // one LDS byte per multiply-add instead of the log + antilog pair, same field arithmetic
-        s[0] ^= d;
-#pragma unroll
-        for (int i = 1; i < NROOTS; i++) s[i] = d ^ mulp[i * 256 + s[i]];
-    }
-    uint32_t syn = 0;
-#pragma unroll
-    for (int i = 0; i < NROOTS; i++) syn |= s[i];
-    if (!syn) return 0;
+// A wavefront runs this path as soon as ONE of its 64 columns has an error, so its cost is set by the
+// worst column of the wave; wave-uniform guards (__any, the wave's largest locator degree) skip the
+// terms that are zero in every lane - after a few single-symbol errors that is most of them.
+__device__ int rs_correct(uint32_t (&s)[NROOTS], uint8_t* col, uint32_t stride, const uint8_t* __restrict__ ato,
+                          const uint8_t* __restrict__ iof, const uint8_t* __restrict__ mulp) {
 #pragma unroll
     for (int i = 0; i < NROOTS; i++) s[i] = iof[s[i]];  // index form (s[10] of the reference is never used)
 
@@ -79,28 +129,38 @@ __device__ int decode_rs(uint8_t* col, const uint8_t* __restrict__ ato, const ui
     for (int r = 1; r <= NROOTS; r++) {  // Berlekamp-Massey (rschecksf.cpp:240-284)
         uint32_t discr = 0;
 #pragma unroll
-        for (int i = 0; i < r; i++)
-            if (lam[i] != 0 && s[r - i - 1] != NN) discr ^= ato[iof[lam[i]] + s[r - i - 1]];
+        for (int i = 0; i < r; i++) {
+            const bool term = lam[i] != 0 && s[r - i - 1] != NN;
+            if (__any(term)) {
+                if (term) discr ^= ato[iof[lam[i]] + s[r - i - 1]];
+            }
+        }
         discr = iof[discr];
         const bool zero = discr == NN;
-        const bool grow = !zero && 2 * el <= r - 1;
-        uint32_t t[NROOTS + 1];
-        t[0] = lam[0];
+        if (__any(!zero)) {
+            const bool grow = !zero && 2 * el <= r - 1;
+            uint32_t t[NROOTS + 1];
+            t[0] = lam[0];
 #pragma unroll
-        for (int i = 0; i < NROOTS; i++) {
-            t[i + 1] = lam[i + 1];
-            if (!zero && b[i] != NN) t[i + 1] ^= ato[discr + b[i]];
+            for (int i = 0; i < NROOTS; i++) {
+                t[i + 1] = lam[i + 1];
+                if (!zero && b[i] != NN) t[i + 1] ^= ato[discr + b[i]];
+            }
+            if (grow) el = r - el;
+            // b <- inv(discr) * lambda (grow) or x * b (otherwise: _mm_slli_si128(b,1), b[0] = 255)
+#pragma unroll
+            for (int i = NROOTS; i >= 0; i--) {
+                const uint32_t scaled = lam[i] == 0 ? (uint32_t)NN : mod255(iof[lam[i]] - discr + NN);
+                const uint32_t shifted = i ? b[i - 1] : (uint32_t)NN;
+                b[i] = grow ? scaled : shifted;
+            }
+#pragma unroll
+            for (int i = 0; i <= NROOTS; i++) lam[i] = zero ? lam[i] : t[i];
+        } else {  // zero discrepancy in every lane: lambda stays, b <- x * b
+#pragma unroll
+            for (int i = NROOTS; i > 0; i--) b[i] = b[i - 1];
+            b[0] = NN;
         }
-        if (grow) el = r - el;
-        // b <- inv(discr) * lambda (grow) or x * b (otherwise: _mm_slli_si128(b,1), b[0] = 255)
-#pragma unroll
-        for (int i = NROOTS; i >= 0; i--) {
-            const uint32_t scaled = lam[i] == 0 ? (uint32_t)NN : mod255(iof[lam[i]] - discr + NN);
-            const uint32_t shifted = i ? b[i - 1] : (uint32_t)NN;
-            b[i] = grow ? scaled : shifted;
-        }
-#pragma unroll
-        for (int i = 0; i <= NROOTS; i++) lam[i] = zero ? lam[i] : t[i];
     }
     int deg_lambda = 0;
 #pragma unroll
@@ -108,73 +168,131 @@ __device__ int decode_rs(uint8_t* col, const uint8_t* __restrict__ ato, const ui
         lam[i] = iof[lam[i]];
         if (lam[i] != NN) deg_lambda = i;
     }
-    // Chien search (rschecksf.cpp:299-320): the reference advances the logs b[j] += j and sums
-    // alpha_to[b[j]]; here the same terms lambda_j * alpha^(j*i) are kept in polynomial form and
-    // advanced with the product tables (one LDS byte per term, no mod-255 arithmetic).
-    uint32_t c[NROOTS + 1];
+    int dmax = 0;  // largest locator degree in this wave (uniform)
 #pragma unroll
-    for (int i = 0; i <= NROOTS; i++) c[i] = lam[i] == NN ? 0u : (uint32_t)ato[lam[i]];
+    for (int d = 1; d <= NROOTS; d++)
+        if (__any(deg_lambda >= d)) dmax = d;
+    dmax = __builtin_amdgcn_readfirstlane(dmax);
+
     uint32_t root[NROOTS];
 #pragma unroll
     for (int k = 0; k < NROOTS; k++) root[k] = 0;
     int count = 0;
-    bool searching = true;
-    for (int i = 1; i <= NN; i++) {
-        if (searching) {
-            uint32_t q = 1;  // lambda[0] is always 1
-#pragma unroll
-            for (int j = NROOTS; j > 0; j--) {
-                c[j] = mulp[j * 256 + c[j]];
-                q ^= c[j];
-            }
-            if (q == 0) {
-#pragma unroll
-                for (int k = 0; k < NROOTS; k++)
-                    if (count == k) root[k] = (uint32_t)i;
-                if (++count == deg_lambda) searching = false;
-            }
+    if (dmax <= 1) {
+        // 1 + lambda_1 * alpha^i = 0 has exactly one solution in i = 1..255: i = 255 - log(lambda_1)
+        if (deg_lambda == 1) {
+            root[0] = (uint32_t)NN - lam[1];
+            count = 1;
         }
-        if (!__any(searching)) break;
+    } else {
+        uint32_t c[NROOTS + 1];
+#pragma unroll
+        for (int i = 0; i <= NROOTS; i++) c[i] = lam[i] == NN ? 0u : (uint32_t)ato[lam[i]];
+        if (dmax <= 2) chien<2>(c, root, count, deg_lambda, mulp);
+        else if (dmax <= 3) chien<3>(c, root, count, deg_lambda, mulp);
+        else if (dmax <= 5) chien<5>(c, root, count, deg_lambda, mulp);
+        else chien<NROOTS>(c, root, count, deg_lambda, mulp);
     }
     if (deg_lambda != count) return -1;
 
     const int deg_omega = deg_lambda - 1;
     uint32_t om[NROOTS];
 #pragma unroll
-    for (int i = 0; i < NROOTS; i++) {  // omega (rschecksf.cpp:331-341)
-        uint32_t tmp = 0;
+    for (int i = 0; i < NROOTS; i++) {  // omega (rschecksf.cpp:331-341); only om[0..deg_omega] is used
+        om[i] = NN;
+        if (i < dmax) {
+            uint32_t tmp = 0;
 #pragma unroll
-        for (int j = 0; j <= i; j++)
-            if (s[i - j] != NN && lam[j] != NN) tmp ^= ato[s[i - j] + lam[j]];
-        om[i] = i <= deg_omega ? (uint32_t)iof[tmp] : (uint32_t)NN;
+            for (int j = 0; j <= i; j++)
+                if (s[i - j] != NN && lam[j] != NN) tmp ^= ato[s[i - j] + lam[j]];
+            om[i] = i <= deg_omega ? (uint32_t)iof[tmp] : (uint32_t)NN;
+        }
     }
     const int top = (deg_lambda < NROOTS - 1 ? deg_lambda : NROOTS - 1) & ~1;
 #pragma unroll
     for (int j = NROOTS - 1; j >= 0; j--) {  // Forney (rschecksf.cpp:346-374)
+        if (j >= dmax) continue;  // count <= dmax in every lane
         const uint32_t rt = root[j];
         if (j < count && rt >= PADN + 1) {  // roots in the virtual padding are skipped, still counted
             uint32_t num1 = 0;
 #pragma unroll
             for (int i = 0; i < NROOTS; i++)
-                if (i <= deg_omega && om[i] != NN) num1 ^= ato[mod255(om[i] + i * rt)];
+                if (i < dmax && i <= deg_omega && om[i] != NN) num1 ^= ato[mod255(om[i] + i * rt)];
             if (num1) {
                 const uint32_t num2 = ato[NN - rt];
                 uint32_t den = 0;
 #pragma unroll
                 for (int i = 0; i < NROOTS; i += 2)
-                    if (i <= top && lam[i + 1] != NN) den ^= ato[mod255(lam[i + 1] + i * rt)];
+                    if (i < dmax && i <= top && lam[i + 1] != NN) den ^= ato[mod255(lam[i + 1] + i * rt)];
                 const uint32_t tmp = (uint32_t)iof[num1] + iof[num2] + (NN - iof[den]);  // <= 763 < 768
-                col[(rt - 1 - PADN) * RS_THREADS] ^= ato[tmp];
+                col[(rt - 1 - PADN) * stride] ^= ato[tmp];
             }
         }
     }
     return count;
 }
 
-// Workgroup = 256 lanes.  For rsdims <= 256 it takes spb = 256/rsdims superframes
-// per pass; for wider superframes it walks the columns in 256-wide chunks, in
+// Transposed-LDS front end (codeword byte k at col[k * RS_THREADS]): Horner syndromes (rschecksf.cpp:212-219)
+// with per-root product tables (mulp[i][x] = x * alpha^i: one LDS byte per multiply-add).
+__device__ int decode_rs(uint8_t* col, const uint8_t* __restrict__ ato, const uint8_t* __restrict__ iof,
+                         const uint8_t* __restrict__ mulp) {
+    uint32_t s[NROOTS];
+    const uint32_t d0 = col[0];
+#pragma unroll
+    for (int i = 0; i < NROOTS; i++) s[i] = d0;
+    for (int j = 1; j < NCW; j++) {
+        const uint32_t d = col[j * RS_THREADS];
+        s[0] ^= d;
+#pragma unroll
+        for (int i = 1; i < NROOTS; i++) s[i] = d ^ mulp[i * 256 + s[i]];
+    }
+    uint32_t syn = 0;
+#pragma unroll
+    for (int i = 0; i < NROOTS; i++) syn |= s[i];
+    if (!syn) return 0;
+    return rs_correct(s, col, RS_THREADS, ato, iof, mulp);
+}
+
+// Natural-layout front end (codeword byte k at col[k * stride]): remainder modulo g(x) by LFSR,
+// r <- r*x + d_k - r_9*(x^10 + g(x)): one 16-byte lookup of the feedback byte per data byte.
+__device__ int decode_rs_lfsr(uint8_t* col, uint32_t stride, const uint8_t* __restrict__ ato,
+                              const uint8_t* __restrict__ iof, const uint8_t* __restrict__ mulp,
+                              const uint32_t* __restrict__ gtab) {
+    uint32_t r0 = 0, r1 = 0, r2 = 0;  // coefficient r_j = byte j of the 80-bit register (r2 above bit 15: junk)
+    const uint8_t* q = col;
+#pragma unroll 8
+    for (int k = 0; k < NCW; k++, q += stride) {
+        const uint32_t d = *q;
+        const uint32_t f = (r2 >> 8) & 0xFFu;  // r_9
+        const uint4 t = *reinterpret_cast<const uint4*>(gtab + f * 4u);
+        r2 = __builtin_amdgcn_alignbit(r2, r1, 24) ^ t.z;
+        r1 = __builtin_amdgcn_alignbit(r1, r0, 24) ^ t.y;
+        r0 = ((r0 << 8) | d) ^ t.x;
+    }
+    r2 &= 0xFFFFu;
+    if ((r0 | r1 | r2) == 0) return 0;
+    // syndromes S_i = r(alpha^i) (= the reference's Horner sums over the whole codeword)
+    uint32_t c[NROOTS];
+#pragma unroll
+    for (int j = 0; j < NROOTS; j++) c[j] = ((j < 4 ? r0 : j < 8 ? r1 : r2) >> (8 * (j & 3))) & 0xFFu;
+    uint32_t s[NROOTS];
+    s[0] = 0;
+#pragma unroll
+    for (int j = 0; j < NROOTS; j++) s[0] ^= c[j];
+#pragma unroll
+    for (int i = 1; i < NROOTS; i++) {
+        uint32_t v = c[NROOTS - 1];
+#pragma unroll
+        for (int j = NROOTS - 2; j >= 0; j--) v = c[j] ^ mulp[i * 256 + v];
+        s[i] = v;
+    }
+    return rs_correct(s, col, stride, ato, iof, mulp);
+}
+
+// General form (used for rsdims > 256).  Workgroup = 256 lanes.  For rsdims <= 256 it takes spb = 256/rsdims
+// superframes per pass; for wider superframes it walks the columns in 256-wide chunks, in
 // order, and stops after the first chunk that holds a failure.
-__global__ __launch_bounds__(RS_THREADS) void rs_kernel(const uint8_t* __restrict__ p, uint8_t* __restrict__ out,
+__global__ __launch_bounds__(RS_THREADS) void rs_kernel_wide(const uint8_t* __restrict__ p, uint8_t* __restrict__ out,
                                                         int32_t* __restrict__ ret, uint32_t rsdims,
                                                         long long nsf) {
     __shared__ uint8_t cw[NCW * RS_THREADS];  // [row][lane]
@@ -232,6 +350,96 @@ __global__ __launch_bounds__(RS_THREADS) void rs_kernel(const uint8_t* __restric
     }
 }
 
+
+// Linear copy of n bytes between global memory and LDS with the widest access the alignment allows.
+template <typename V>
+__device__ __forceinline__ void copy_vec(uint8_t* dst, const uint8_t* src, uint32_t n, uint32_t tid) {
+    const uint32_t nv = n / (uint32_t)sizeof(V);
+    for (uint32_t i = tid; i < nv; i += RS_THREADS) reinterpret_cast<V*>(dst)[i] = reinterpret_cast<const V*>(src)[i];
+    for (uint32_t i = nv * (uint32_t)sizeof(V) + tid; i < n; i += RS_THREADS) dst[i] = src[i];
+}
+__device__ __forceinline__ void copy_linear(uint8_t* dst, const uint8_t* src, uint32_t n, uint32_t tid) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src);
+    if ((a & 15u) == 0) copy_vec<uint4>(dst, src, n, tid);
+    else if ((a & 7u) == 0) copy_vec<uint2>(dst, src, n, tid);
+    else if ((a & 3u) == 0) copy_vec<uint32_t>(dst, src, n, tid);
+    else copy_vec<uint8_t>(dst, src, n, tid);
+}
+
+// rsdims <= 256: spb = 256/rsdims superframes per pass, natural layout in LDS (see the header comment).
+__global__ __launch_bounds__(RS_THREADS) void rs_kernel(const uint8_t* __restrict__ p, uint8_t* __restrict__ out,
+                                                        int32_t* __restrict__ ret, uint32_t rsdims,
+                                                        long long nsf) {
+    __shared__ __attribute__((aligned(16))) uint8_t cw[NCW * RS_THREADS];  // [superframe][row][column]
+    __shared__ __attribute__((aligned(16))) uint32_t gtab[256 * 4];
+    __shared__ uint8_t ato[768];
+    __shared__ uint8_t iof[256];
+    __shared__ uint8_t mulp[(NROOTS + 1) * 256];  // mulp[i][x] = x * alpha^i, i = 0..10
+    __shared__ int s_minfail[RS_THREADS];
+    __shared__ int s_sum[RS_THREADS];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < 768; i += RS_THREADS) ato[i] = g_gf.ato[i];
+    iof[tid] = g_gf.iof[tid];
+    for (int i = 0; i <= NROOTS; i++) mulp[i * 256 + tid] = tid ? g_gf.ato[g_gf.iof[tid] + i] : 0;
+    for (uint32_t i = tid; i < 256u * 4u; i += RS_THREADS) gtab[i] = g_gen.w[i];
+    __syncthreads();
+
+    const uint32_t spb = RS_THREADS / rsdims;
+    const long long ngroups = (nsf + spb - 1) / spb;
+    const uint32_t in_sz = NCW * rsdims, out_sz = NMSG * rsdims;
+    const uint32_t lsf = tid / rsdims, colidx = tid - lsf * rsdims;
+    constexpr int NOFAIL = 0x7FFFFFFF;
+
+    for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const long long sf0 = g * spb;
+        const uint32_t nloc = nsf - sf0 < (long long)spb ? (uint32_t)(nsf - sf0) : spb;
+        if (tid < spb) {
+            s_minfail[tid] = NOFAIL;
+            s_sum[tid] = 0;
+        }
+        copy_linear(cw, p + (size_t)sf0 * in_sz, nloc * in_sz, tid);
+        __syncthreads();
+        const bool active = lsf < nloc;
+        int res = 0;
+        if (active) {
+            res = decode_rs_lfsr(cw + lsf * in_sz + colidx, rsdims, ato, iof, mulp, gtab);
+            if (res < 0) atomicMin(&s_minfail[lsf], (int)colidx);
+        }
+        __syncthreads();
+        uint8_t* dst0 = out + (size_t)sf0 * out_sz;
+        // superframes without a failure: their first 110 rows go out as one linear block each
+        if ((out_sz & 3u) == 0 && (reinterpret_cast<uintptr_t>(dst0) & 3u) == 0) {
+            const uint32_t wps = out_sz >> 2;  // dwords per superframe; in_sz is a multiple of 8
+            for (uint32_t c = tid; c < nloc * wps; c += RS_THREADS) {
+                const uint32_t l = c / wps, o = c - l * wps;
+                if (s_minfail[l] == NOFAIL)
+                    reinterpret_cast<uint32_t*>(dst0 + (size_t)l * out_sz)[o] =
+                        reinterpret_cast<const uint32_t*>(cw + l * in_sz)[o];
+            }
+            if (active) {
+                const int mf = s_minfail[lsf];
+                if (mf != NOFAIL && (int)colidx < mf) {  // columns before the first failure are written
+                    uint8_t* dst = dst0 + (size_t)lsf * out_sz + colidx;
+                    const uint8_t* src = cw + lsf * in_sz + colidx;
+                    for (int k = 0; k < NMSG; k++) dst[(size_t)k * rsdims] = src[k * rsdims];
+                }
+                if ((int)colidx < mf) atomicAdd(&s_sum[lsf], res);
+            }
+        } else if (active) {
+            const int mf = s_minfail[lsf];
+            if ((int)colidx < mf) {
+                uint8_t* dst = dst0 + (size_t)lsf * out_sz + colidx;
+                const uint8_t* src = cw + lsf * in_sz + colidx;
+                for (int k = 0; k < NMSG; k++) dst[(size_t)k * rsdims] = src[k * rsdims];
+                atomicAdd(&s_sum[lsf], res);
+            }
+        }
+        __syncthreads();
+        if (tid < nloc) ret[sf0 + tid] = s_minfail[tid] != NOFAIL ? -1 : s_sum[tid];
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 hipError_t rs_launch(const uint8_t* d_p, uint8_t* d_out, int32_t* d_ret, uint32_t rsdims, int64_t nsf,
@@ -240,7 +448,11 @@ hipError_t rs_launch(const uint8_t* d_p, uint8_t* d_out, int32_t* d_ret, uint32_
     const uint32_t spb = rsdims <= RS_THREADS ? RS_THREADS / rsdims : 1u;
     long long groups = (nsf + spb - 1) / spb;
     if (groups > (1 << 20)) groups = 1 << 20;
-    hipLaunchKernelGGL(rs_kernel, dim3((unsigned)groups), dim3(RS_THREADS), 0, stream, d_p, d_out, d_ret, rsdims,
-                       (long long)nsf);
+    if (rsdims <= RS_THREADS)
+        hipLaunchKernelGGL(rs_kernel, dim3((unsigned)groups), dim3(RS_THREADS), 0, stream, d_p, d_out, d_ret, rsdims,
+                           (long long)nsf);
+    else
+        hipLaunchKernelGGL(rs_kernel_wide, dim3((unsigned)groups), dim3(RS_THREADS), 0, stream, d_p, d_out, d_ret,
+                           rsdims, (long long)nsf);
     return hipGetLastError();
 }

@@ -253,6 +253,9 @@ __device__ int decode_rs(uint8_t* col, const uint8_t* __restrict__ ato, const ui
     return rs_correct(s, col, RS_THREADS, ato, iof, mulp);
 }
 
+struct __attribute__((aligned(16))) G3 {
+    uint32_t x, y, z;
+};
 // Natural-layout front end (codeword byte k at col[k * stride]): remainder modulo g(x) by LFSR,
 // r <- r*x + d_k - r_9*(x^10 + g(x)): one 16-byte lookup of the feedback byte per data byte.
 __device__ int decode_rs_lfsr(uint8_t* col, uint32_t stride, const uint8_t* __restrict__ ato,
@@ -264,7 +267,7 @@ __device__ int decode_rs_lfsr(uint8_t* col, uint32_t stride, const uint8_t* __re
     for (int k = 0; k < NCW; k++, q += stride) {
         const uint32_t d = *q;
         const uint32_t f = (r2 >> 8) & 0xFFu;  // r_9
-        const uint4 t = *reinterpret_cast<const uint4*>(gtab + f * 4u);
+        const G3 t = *reinterpret_cast<const G3*>(gtab + f * 4u);  // ds_read_b96: 10 of the 16 bytes are payload
         r2 = __builtin_amdgcn_alignbit(r2, r1, 24) ^ t.z;
         r1 = __builtin_amdgcn_alignbit(r1, r0, 24) ^ t.y;
         r0 = ((r0 << 8) | d) ^ t.x;

@@ -29,6 +29,11 @@ a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True
 a.record()
 for _ in range(10): V.rs_batch_dev(d_p, d_out, d_ret, rsdims, nsf)
 b.record(); torch.cuda.synchronize(); ms = a.elapsed_time(b) / 10
+import time
+t0 = time.perf_counter()
+for _ in range(20): O.rs_check_batch(p, rsdims)
+cpu_us = (time.perf_counter() - t0) / (20 * base_n) * 1e6  # oracle (scalar C port), 1 thread, incl. ctypes call overhead
 ok = bool(np.array_equal(d_ret[:base_n].cpu().numpy(), ret_ref)) and bool(np.array_equal(d_out[:base_n].cpu().numpy(), out_ref))
 print(json.dumps({"rsdims": rsdims, "nsf": nsf, "mode": mode, "ms": round(ms, 4), "Mcolumns_s": round(nsf * rsdims / ms / 1e3, 1),
-                  "GB_s": round(nsf * 230 * rsdims / ms / 1e6, 1), "parity_ok": ok}))
+                  "GB_s": round(nsf * 230 * rsdims / ms / 1e6, 1), "hbm_frac": round(nsf * 230 * rsdims / ms / 1e6 / 8000.0, 3),
+                  "cpu_oracle_us_per_superframe_1thread": round(cpu_us, 2), "gpu_ns_per_superframe": round(ms * 1e6 / nsf, 2), "parity_ok": ok}))

@@ -209,3 +209,48 @@ def test_packed_layout_emulation(O):
     for fb in (40, 136):
         sym = np.concatenate([O.noisy_frames(2, fb, seed=fb), O.uniform_symbols(2 * O.sym_len(fb), seed=fb + 1).reshape(2, -1)])
         assert np.array_equal(emu.emulate(sym, fb), O.decode_batch(fb, sym))
+
+
+def test_rs_syndromes_from_generator_remainder():
+    """CPU check of the identity csrc/rs_kernels.hip relies on: the ten syndromes of the reference's
+    Horner loop (rschecksf.cpp:210-219) equal the remainder of the codeword modulo
+    g(x) = prod_{i=0..9}(x + alpha^i) evaluated at alpha^i; a valid codeword has remainder 0."""
+    alpha, iof, sr = [0] * 255, [255] * 256, 1
+    for i in range(255):  # dllmain.cpp:124-146
+        iof[sr], alpha[i] = i, sr
+        sr <<= 1
+        if sr & 256:
+            sr ^= 285
+        sr &= 255
+
+    def mul(a, b):
+        return 0 if a == 0 or b == 0 else alpha[(iof[a] + iof[b]) % 255]
+
+    g = [1]
+    for i in range(10):
+        ng = [0] * (len(g) + 1)
+        for j, c in enumerate(g):
+            ng[j + 1] ^= c
+            ng[j] ^= mul(c, alpha[i])
+        g = ng
+    assert g[10] == 1 and g[:10] == [193, 157, 113, 95, 94, 199, 111, 159, 194, 216]
+    rng = np.random.default_rng(9)
+    import _vitpkg
+    O = _vitpkg.load_oracle()
+    for trial in range(40):
+        d = rng.integers(0, 256, 120).tolist() if trial % 2 else O.rs_encode(rng.integers(0, 256, 110, dtype=np.uint8)).tolist()
+        S = [d[0]] * 10
+        for k in range(1, 120):
+            S = [mul(S[i], alpha[i]) ^ d[k] for i in range(10)]
+        r = [0] * 10
+        for k in range(120):  # r <- r*x + d_k mod g
+            f = r[9]
+            r = [d[k] ^ mul(f, g[0])] + [r[j - 1] ^ mul(f, g[j]) for j in range(1, 10)]
+        S2 = []
+        for i in range(10):
+            v = r[9]
+            for j in range(8, -1, -1):
+                v = mul(v, alpha[i]) ^ r[j]
+            S2.append(v)
+        assert S == S2
+        assert (trial % 2 == 1) or (r == [0] * 10 and S == [0] * 10)

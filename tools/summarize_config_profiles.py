@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""gpurun_out/configs_<tag>/ (tools/collect_config_profiles.sh) -> committed summaries under profiles/."""
+import collections
+import csv
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", "configs_" + tag)
+dst = os.path.join(root, "profiles")
+OURS = ("vit_pk", "vit_wave", "vit_pack", "rs_kernel", "desc_")
+
+with open(os.path.join(dst, "%s_other_configs.jsonl" % tag), "w") as f:
+    for name in ("configs.jsonl", "rs.jsonl", "hostpaths.jsonl"):
+        for line in open(os.path.join(src, name)):
+            if line.startswith("{"):
+                f.write(line)
+shutil.copy(os.path.join(src, "vitbench.txt"), os.path.join(dst, "%s_vitbench.txt" % tag))
+with open(os.path.join(dst, "%s_soak.txt" % tag), "w") as f:
+    f.write("# tools/soak.py on MI355X: GPU (auto kernel) vs CPU oracle, bit-exact compare of every output byte\n"
+            "# decode: lengths 768/288/1536/3072/6912/9216/776/784 x {Eb/N0 3 dB, 0 dB, uniform random bytes};\n"
+            "# RS: random superframes with 0..8 symbol errors per column, RSDims 24/12/5/1/37/256/300\n")
+    for line in open(os.path.join(src, "soak.jsonl")):
+        if "total_frames" in line or "rs_superframes" in line or '"rsdims"' in line:
+            f.write(line)
+
+out = ["# %s - rocprofv3 --kernel-trace --stats -- python3 tools/bench_configs.py  (this repo's kernels only)\n" % tag]
+for r in csv.DictReader(open(os.path.join(src, "kernel_stats.csv"))):
+    if any(k in r["Name"] for k in OURS):
+        out.append("%-64.64s calls=%-4s avg_us=%9.1f min_us=%9.1f max_us=%9.1f\n" % (
+            r["Name"].replace("(anonymous namespace)::", ""), r["Calls"], float(r["AverageNs"]) / 1e3,
+            float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
+out.append("\n# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of the same script, mean per launch, grouped by\n"
+           "# kernel and grid size; HBM bytes = 2*FETCH_SIZE*1024 (gfx950 correction, MI355X_MICROARCH.md) and WRITE_SIZE*1024\n")
+agg = collections.defaultdict(dict)
+for p, cname in (("p1", "FETCH_SIZE"), ("p2", "WRITE_SIZE")):
+    tmp = collections.defaultdict(list)
+    for r in csv.DictReader(open(os.path.join(src, "pmc_%s.csv" % p))):
+        if any(k in r["Kernel_Name"] for k in OURS) and r["Counter_Name"] == cname:
+            tmp[(r["Kernel_Name"].replace("(anonymous namespace)::", "")[:48], r["Grid_Size"])].append(float(r["Counter_Value"]))
+    for k, v in tmp.items():
+        agg[k][cname] = sum(v) / len(v)
+for (name, grid), c in sorted(agg.items()):
+    rd = 2.0 * c.get("FETCH_SIZE", 0) * 1024
+    wr = c.get("WRITE_SIZE", 0) * 1024
+    out.append("%-48s grid=%-9s read %9.1f MB  write %9.1f MB\n" % (name, grid, rd / 1e6, wr / 1e6))
+out.append("\n# reading the table: config 5 (grid 229376 = 3584 persistent workgroups, 81920 frames of 4608 bits) reads 1512 MB of\n"
+           "# symbols + 2852 MB of spilled decisions and writes 2852 MB of spill + 47 MB of output: the spill is 16 B per\n"
+           "# frame-step by design (DESIGN.md), 7.2 GB per 3.85 ms launch = 1.9 TB/s on a VALU-bound kernel.\n")
+open(os.path.join(dst, "%s_config_kernels.txt" % tag), "w").writelines(out)
+print("".join(out))

@@ -11,6 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 python3 $R/tools/bench_configs.py > $OUT/configs.jsonl 2> $OUT/configs.err; echo "configs rc=$?"
 for m in clean light mixed; do python3 $R/tools/bench_rs.py 24 131072 $m 2>/dev/null; done > $OUT/rs.jsonl; echo "rs rc=$?"
 python3 $R/tools/bench_host_paths.py > $OUT/hostpaths.jsonl 2>/dev/null; echo "host rc=$?"
+[ -x $R/tools/vitbench.bin ] || g++ -O2 -std=c++17 -I $R/include -o $R/tools/vitbench.bin $R/tools/vitbench.cpp -ldl -lpthread
 $R/tools/vitbench.bin $R/viterbi.dll_amd/libviterbi.so > $OUT/vitbench.txt 2>&1; echo "vitbench rc=$?"
 python3 $R/tools/soak.py > $OUT/soak.jsonl 2>/dev/null; echo "soak rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/tools/bench_configs.py > $OUT/kt.log 2>&1; echo "kt rc=$?"

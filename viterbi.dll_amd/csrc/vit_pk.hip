@@ -96,6 +96,9 @@ struct Lanes {
 #ifndef VIT_K3
 #define VIT_K3 0
 #endif
+#ifndef VIT_STEPS6
+#define VIT_STEPS6 1  /* skip the ten padding steps of the last block when T = 6 mod 16 */
+#endif
 #ifndef VIT_PRIO
 #define VIT_PRIO 1  /* measured: ~1 % on the 65536-frame batch */
 #endif
@@ -193,29 +196,37 @@ DEV void acs_step(u32& A, u32& B, u32& acc0, u32& acc1, u32 mt, u32 lane, const 
     }
 }
 
-template <int V, int J, bool HIST>
+template <int V, int J, int JEND, bool HIST>
 struct Steps {
     static DEV void run(u32& A, u32& B, u32& acc0, u32& acc1, const char* tab, const Lanes& L, u32 lane,
                         const Consts& C) {
         constexpr int RHO = (V + J) % 5;
         const u32 mt = *reinterpret_cast<const u32*>(tab + L.toff[RHO] + J * 64);
         acs_step<RHO, J, HIST>(A, B, acc0, acc1, mt, lane, C);
-        Steps<V, J + 1, HIST>::run(A, B, acc0, acc1, tab, L, lane, C);
+        Steps<V, J + 1, JEND, HIST>::run(A, B, acc0, acc1, tab, L, lane, C);
     }
 };
-template <int V, bool HIST>
-struct Steps<V, 16, HIST> {
+template <int V, int JEND, bool HIST>
+struct Steps<V, JEND, JEND, HIST> {
     static DEV void run(u32&, u32&, u32&, u32&, const char*, const Lanes&, u32, const Consts&) {}
 };
-template <bool HIST>
+template <bool HIST, int N = 16>
 DEV void steps16(u32 v, u32& A, u32& B, u32& acc0, u32& acc1, const char* th, const Lanes& L, u32 lane, const Consts& C) {
     switch (v) {
-        case 0: Steps<0, 0, HIST>::run(A, B, acc0, acc1, th, L, lane, C); break;
-        case 1: Steps<1, 0, HIST>::run(A, B, acc0, acc1, th, L, lane, C); break;
-        case 2: Steps<2, 0, HIST>::run(A, B, acc0, acc1, th, L, lane, C); break;
-        case 3: Steps<3, 0, HIST>::run(A, B, acc0, acc1, th, L, lane, C); break;
-        default: Steps<4, 0, HIST>::run(A, B, acc0, acc1, th, L, lane, C); break;
+        case 0: Steps<0, 0, N, HIST>::run(A, B, acc0, acc1, th, L, lane, C); break;
+        case 1: Steps<1, 0, N, HIST>::run(A, B, acc0, acc1, th, L, lane, C); break;
+        case 2: Steps<2, 0, N, HIST>::run(A, B, acc0, acc1, th, L, lane, C); break;
+        case 3: Steps<3, 0, N, HIST>::run(A, B, acc0, acc1, th, L, lane, C); break;
+        default: Steps<4, 0, N, HIST>::run(A, B, acc0, acc1, th, L, lane, C); break;
     }
+}
+// Last block of a frame whose step count is 6 mod 16 - every DAB size (framebits = 96*m, and the FIC's
+// 768): the ten padding steps are not computed.  After six steps the history sits at bits 7..12 of
+// each half (see acs_step); one more shift puts step j at bit j like in a full block.
+DEV void steps6(u32 v, u32& A, u32& B, u32& acc0, u32& acc1, const char* th, const Lanes& L, u32 lane, const Consts& C) {
+    steps16<true, 6>(v, A, B, acc0, acc1, th, L, lane, C);
+    acc0 >>= 7;
+    acc1 >>= 7;
 }
 
 // The 8 pavgb-tree metrics of one frame-step: s = its 4 soft symbols (bytes), ns = ~s.
@@ -544,7 +555,10 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
                 sb = tn < b_T ? load_step<SYM32>(b_sym, tn) : 0u;
                 __syncthreads();
             }
-            steps16<true>(v, A, B, acc0, acc1, tab + (rb & 1u) * 1024u, L, lane, C);
+            if (VIT_STEPS6 && rb + 1u == nb && (T_max & 15u) == 6u)
+                steps6(v, A, B, acc0, acc1, tab + (rb & 1u) * 1024u, L, lane, C);
+            else
+                steps16<true>(v, A, B, acc0, acc1, tab + (rb & 1u) * 1024u, L, lane, C);
             if (rb < R) {
                 r0[rb] = acc0;  // s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off
                 r1[rb] = acc1;
@@ -713,7 +727,10 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
                     sb = tn < b_T ? load_step<SYM32>(b_sym, tn) : 0u;
                     __syncthreads();
                 }
-                steps16<true>(v, A, B, acc0, acc1, tab + (rb & 1u) * 1024u, L, lane, C);
+                if (VIT_STEPS6 && rb + 1u == nblk && (T_max & 15u) == 6u)
+                    steps6(v, A, B, acc0, acc1, tab + (rb & 1u) * 1024u, L, lane, C);
+                else
+                    steps16<true>(v, A, B, acc0, acc1, tab + (rb & 1u) * 1024u, L, lane, C);
                 if (rb < G) {
                     wspill[(size_t)rb * 64u] = make_uint2(acc0, acc1);
                 } else {

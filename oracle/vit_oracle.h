@@ -9,9 +9,15 @@
  *
  * Pinning status: the reference cannot be compiled in this image without
  * writing stand-ins for <windows.h>/<psapi.h> and restating const.asm (MASM),
- * so there is no oracle/_ref build.  The oracle is pinned by the known-answer
- * vectors recorded in SURVEY.md section 8c (outputs of the compiled reference
- * taken during the survey) -- see tests/golden/ and tests/test_oracle_kat.py.
+ * so there is no oracle/_ref build, and the reference ships no golden vectors
+ * of its own.  The oracle is pinned by the known-answer vectors recorded in
+ * SURVEY.md section 8c (outputs of the compiled reference taken during the
+ * survey: the 16-byte decoder prefix for framebits 288/768/6912, GF table
+ * samples, two RScheckSuperframe behaviours) -- see tests/test_oracle_kat.py.
+ * Beyond those vectors: PARITY UNPINNED (the survey's three full-length
+ * FNV-1a digests could not be reproduced and are carried as a tripwire only);
+ * tests/golden/ holds regression vectors made by this oracle, not reference
+ * outputs.
  */
 #ifndef VIT_ORACLE_H
 #define VIT_ORACLE_H

@@ -86,17 +86,19 @@ int vit_device_count(void);
 /* Frame descriptor for variable-length batches.
  * sym_offset: byte offset of the frame's first soft symbol in the u8 symbol
  * buffer, multiple of 4; the frame owns 4*(framebits+6) bytes from there.
- * out_offset: byte offset of its framebits/8 output bytes. */
+ * out_offset: byte offset of its (framebits+7)/8 output bytes. */
 typedef struct vit_frame_desc {
     uint64_t sym_offset;
     uint64_t out_offset;
-    uint32_t framebits; /* even, multiple of 8, <= 9216 */
+    uint32_t framebits; /* even, <= 9216 */
     uint32_t reserved;
 } vit_frame_desc;
 
 /* Device format of the soft symbols: one byte per symbol (the low byte of the
  * reference's u32), frames back to back: frame f at f*4*(framebits+6).
- * Decoded output: frame f at f*(framebits/8).
+ * Decoded output: frame f at f*((framebits+7)/8), MSB first; framebits may be
+ * any even number up to 9216 (a partial last byte is padded with zero bits,
+ * like the reference's ChainBack writes it).
  * All *_dev calls take DEVICE pointers and enqueue on `stream` (a hipStream_t,
  * NULL = default stream) without synchronising. */
 int vit_decode_batch_dev(const uint8_t *d_symbols_u8, uint8_t *d_decoded,
@@ -109,9 +111,8 @@ int vit_decode_batch_dev_u32(const uint32_t *d_symbols_u32, uint8_t *d_decoded,
                              uint32_t framebits, int64_t nframes, void *stream);
 /* Variable-length batch; d_desc is a DEVICE array of nframes descriptors,
  * max_framebits the largest framebits in it (host-known).  A descriptor whose
- * framebits exceeds max_framebits is skipped (its output bytes stay untouched);
- * if any framebits is not a multiple of 8 the whole batch must go through
- * vit_set_kernel(1), the wave-per-frame kernel.  Tables of 16 or more frames
+ * framebits exceeds max_framebits (or is odd) is skipped: its output bytes stay
+ * untouched.  Tables of 16 or more frames
  * are length-sorted on the device into an internal copy first (longest frame
  * first: a wavefront decodes four consecutive descriptors and runs as long as
  * the longest); d_desc itself is never modified and the order changes no

@@ -102,10 +102,10 @@ def deconvolve_u32(framebits, sym_u32, ge=False):
 
 
 def decode_batch(framebits, sym_u8, nthreads=1, avx2=False):
-    """sym_u8: (nframes, 4*(framebits+6)) uint8 -> (nframes, framebits//8) uint8"""
+    """sym_u8: (nframes, 4*(framebits+6)) uint8 -> (nframes, (framebits+7)//8) uint8"""
     sym_u8 = np.ascontiguousarray(sym_u8, np.uint8).reshape(-1, sym_len(framebits))
     n = sym_u8.shape[0]
-    out = np.zeros((n, framebits // 8), np.uint8)
+    out = np.zeros((n, (framebits + 7) // 8), np.uint8)
     fn = lib().vo_decode_batch_avx2_u8 if avx2 else lib().vo_decode_batch_u8
     rc = fn(framebits, _p(sym_u8), _p(out), n, nthreads)
     if rc != 0:

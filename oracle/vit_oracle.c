@@ -134,7 +134,7 @@ struct vo_job {
 };
 static void *vo_worker(void *p) {
     struct vo_job *j = (struct vo_job *)p;
-    size_t ssz = 4u * (j->framebits + 6), osz = j->framebits / 8;
+    size_t ssz = 4u * (j->framebits + 6), osz = (j->framebits + 7) / 8; /* a partial last byte is written too (ChainBack: out[n>>3]) */
     for (long f = j->f0; f < j->f1; f++)
         j->fn(j->framebits, j->sym + ssz * f, j->out + osz * f);
     return NULL;

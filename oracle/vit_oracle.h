@@ -41,7 +41,7 @@ int vo_deconvolve_opt(unsigned framebits, const uint32_t *symbols,
 int vo_deconvolve_u8(unsigned framebits, const uint8_t *symbols,
                      unsigned char *out);
 /* Batch helpers (frames contiguous; u8 symbols, 4*(framebits+6) per frame;
- * framebits/8 output bytes per frame).  nthreads<=1 -> serial. */
+ * (framebits+7)/8 output bytes per frame).  nthreads<=1 -> serial. */
 int vo_decode_batch_u8(unsigned framebits, const uint8_t *symbols,
                        unsigned char *out, long nframes, int nthreads);
 

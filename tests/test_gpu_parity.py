@@ -18,7 +18,7 @@ def _gpu_decode(V, torch, sym, framebits, kernel):
     old = V.set_kernel(kernel)
     try:
         d_sym = torch.from_numpy(np.ascontiguousarray(sym)).cuda()
-        d_out = torch.full((n, framebits // 8), 0xEE, dtype=torch.uint8, device="cuda")
+        d_out = torch.full((n, (framebits + 7) // 8), 0xEE, dtype=torch.uint8, device="cuda")
         V.decode_batch_dev(d_sym, d_out, framebits, n)
         torch.cuda.synchronize()
         return d_out.cpu().numpy()
@@ -34,7 +34,7 @@ def _mixed_input(O, n, framebits, seed):
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
-@pytest.mark.parametrize("framebits", [768, 288, 1536, 2304, 3072, 8, 16, 96])
+@pytest.mark.parametrize("framebits", [768, 288, 1536, 2304, 3072, 8, 16, 96, 2, 10, 770, 778, 780, 1542, 3070])
 def test_decode_parity_uniform_length(V, O, torch_cuda, framebits, kernel):
     n = 203 if framebits <= 3072 else 37  # not a multiple of 4: ragged last group
     sym = _mixed_input(O, n, framebits, seed=framebits + 1)
@@ -44,7 +44,7 @@ def test_decode_parity_uniform_length(V, O, torch_cuda, framebits, kernel):
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
-@pytest.mark.parametrize("framebits", [6912, 9216])
+@pytest.mark.parametrize("framebits", [6912, 9216, 9214, 5002])
 def test_decode_parity_long_frames(V, O, torch_cuda, framebits, kernel):
     n = 13
     sym = _mixed_input(O, n, framebits, seed=framebits)
@@ -186,10 +186,11 @@ def test_u32_ingest_path(V, O, torch_cuda, framebits, n):
 
 @pytest.mark.parametrize("kernel", [0, 1, 2])
 def test_varlen_batch(V, O, torch_cuda, kernel):
-    """BASELINE config 3 in small: framebits = 96*m, m in 3..72, descriptor table"""
+    """BASELINE config 3 in small: framebits = 96*m, m in 3..72, descriptor table (+ lengths that are
+    not multiples of 8: a partial last byte per frame)"""
     torch = torch_cuda
     rng = np.random.default_rng(1)
-    fbs = (96 * rng.integers(3, 73, 97)).tolist() + [8, 9216]
+    fbs = (96 * rng.integers(3, 73, 97)).tolist() + [8, 9216, 2, 770, 4098, 9214, 30]  # any even length
     desc, sym_bytes, out_bytes = V.make_descs(fbs)
     sym = O.uniform_symbols(sym_bytes, seed=4)
     want = np.concatenate([O.decode_batch(fb, sym[int(d["sym_offset"]):int(d["sym_offset"]) + O.sym_len(fb)])[0]
@@ -214,7 +215,7 @@ def test_random_lengths_and_batch_sizes(V, O, torch_cuda):
     rng = np.random.default_rng(2025)
     edges = [8, 16, 24, 104, 112, 120, 248, 256, 264, 272, 504, 512, 520, 760, 768, 776, 784, 792, 1544, 1552, 1560,
              2336, 3128, 3136, 4096, 4104, 7840, 9208, 9216]
-    lengths = sorted(set(edges + (8 * rng.integers(1, 1153, 12)).tolist()))
+    lengths = sorted(set(edges + (8 * rng.integers(1, 1153, 12)).tolist() + (2 * rng.integers(1, 4609, 12)).tolist()))
     for fb in lengths:
         n = int(rng.integers(1, 10))
         sym = _mixed_input(O, n, fb, seed=fb) if n > 1 else O.noisy_frames(1, fb, seed=fb)

@@ -149,7 +149,7 @@ def RScheckSuperframe(p, startIx, RSDims, outVector=None):
 def decode_batch_host(symbols_u8, framebits):
     symbols_u8 = np.ascontiguousarray(symbols_u8, np.uint8).reshape(-1, 4 * (framebits + TAIL))
     n = symbols_u8.shape[0]
-    out = np.zeros((n, framebits // 8), np.uint8)
+    out = np.zeros((n, (framebits + 7) // 8), np.uint8)
     _check(lib().vit_decode_batch_host(_np(symbols_u8), _np(out), framebits, n), "vit_decode_batch_host")
     return out
 
@@ -219,7 +219,7 @@ def make_descs(framebits_list, sym_align=4):
     """Contiguous layout for a variable-length batch -> (desc array, sym bytes, out bytes)."""
     fb = np.asarray(framebits_list, np.int64)
     sym_sz = 4 * (fb + TAIL)
-    out_sz = fb // 8
+    out_sz = (fb + 7) // 8
     d = np.zeros(fb.size, DESC_DTYPE)
     d["framebits"] = fb
     d["sym_offset"] = np.concatenate(([0], np.cumsum(sym_sz)[:-1]))

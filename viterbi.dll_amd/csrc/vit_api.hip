@@ -170,8 +170,9 @@ bool valid_framebits(uint32_t fb) { return fb <= VIT_MAX_FRAMEBITS && (fb & 1u) 
 // the analogue of setupdll.cpp:195-270's dispatcher: choose the kernel for a batch
 bool packed_kernel_selected(const vit_frame_desc* d_desc, uint32_t framebits, uint32_t max_framebits, bool* forced_bad) {
     const int k = g_kernel.load();
-    const bool pk_ok = (max_framebits % 8u) == 0 && (!d_desc ? (framebits % 8u) == 0 : true) &&
-                       vit_pk_supported(max_framebits);
+    (void)d_desc;
+    (void)framebits;
+    const bool pk_ok = vit_pk_supported(max_framebits);  // every even length up to 9216
     if (forced_bad) *forced_bad = (k == 2 && !pk_ok);
     return k == 1 ? false : pk_ok;
 }
@@ -470,7 +471,7 @@ static int deconvolve_impl(unsigned int framebits, unsigned int* symbols, unsign
         set_err("deconvolve: bad arguments (framebits=%u)", framebits);
         return 1;
     }
-    if (g_batcher->window_us.load() > 0 && (framebits % 8u) == 0) {
+    if (g_batcher->window_us.load() > 0) {
         if (hip_device_ready() != VIT_OK) return 1;
         if (g_batcher->submit(framebits, symbols, decodedBits) != VIT_OK) {
             g_fault.store(1);

@@ -496,13 +496,13 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
                 fbits[k] = desc[f].framebits;
                 soff[k] = desc[f].sym_offset;
                 ooff[k] = desc[f].out_offset;
-                // a descriptor the launch was not sized for (longer than max_framebits, or not a
-                // multiple of 8) is skipped rather than allowed to run off the LDS layout
-                if (fbits[k] > lay.maxfb || (fbits[k] & 7u)) fbits[k] = 0;
+                // a descriptor the launch was not sized for (longer than max_framebits, or odd) is
+                // skipped rather than allowed to run off the LDS layout
+                if (fbits[k] > lay.maxfb || (fbits[k] & 1u)) fbits[k] = 0;
             } else {
                 fbits[k] = framebits_uniform;
                 soff[k] = (size_t)f * 4u * (framebits_uniform + VIT_TAIL);
-                ooff[k] = (size_t)f * (framebits_uniform >> 3);
+                ooff[k] = (size_t)f * ((framebits_uniform + 7u) >> 3);
             }
         }
         maxfb = fbits[k] > maxfb ? fbits[k] : maxfb;
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
     // bit b of the image is decoded bit b; output bytes are MSB-first (deconvolve.cpp:432-433)
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const u32 nbytes = fbits[k] >> 3;
+        const u32 nbytes = (fbits[k] + 7u) >> 3;  // a partial last byte is padded with zero bits (ChainBack starts from E = 0)
         uint8_t* o = out + ooff[k];
         if (((ooff[k] | nbytes) & 3u) == 0) {
             for (u32 m = lane; m < (nbytes >> 2); m += 64u)
@@ -692,11 +692,11 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
                     fbits[k] = desc[f].framebits;
                     soff[k] = desc[f].sym_offset;
                     ooff[k] = desc[f].out_offset;
-                    if (fbits[k] > lay.maxfb || (fbits[k] & 7u)) fbits[k] = 0;  // not what the launch was sized for
+                    if (fbits[k] > lay.maxfb || (fbits[k] & 1u)) fbits[k] = 0;  // not what the launch was sized for
                 } else {
                     fbits[k] = framebits_uniform;
                     soff[k] = (size_t)f * 4u * (framebits_uniform + VIT_TAIL);
-                    ooff[k] = (size_t)f * (framebits_uniform >> 3);
+                    ooff[k] = (size_t)f * ((framebits_uniform + 7u) >> 3);
                 }
             }
             maxfb = fbits[k] > maxfb ? fbits[k] : maxfb;
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
         // ---- output bytes, MSB first (deconvolve.cpp:432-433) ----
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const u32 nbytes = fbits[k] >> 3;
+            const u32 nbytes = (fbits[k] + 7u) >> 3;  // a partial last byte is padded with zero bits (ChainBack starts from E = 0)
             uint8_t* o = out + ooff[k];
             if (((ooff[k] | nbytes) & 3u) == 0) {
                 for (u32 m = lane; m < (nbytes >> 2); m += 64u)
@@ -794,7 +794,7 @@ constexpr u32 PK_MAX_FRAMEBITS = VIT_MAX_FRAMEBITS;
 }  // namespace
 
 bool vit_pk_supported(uint32_t max_framebits) {
-    if (max_framebits < 8 || max_framebits > PK_MAX_FRAMEBITS || (max_framebits % 8u) != 0) return false;
+    if (max_framebits < 2 || max_framebits > PK_MAX_FRAMEBITS || (max_framebits % 2u) != 0) return false;
     const u32 nblk = (max_framebits + VIT_TAIL + 15u) >> 4;
     return (nblk <= SEG_BLOCKS ? pk_layout(max_framebits) : pk_layout_long(max_framebits)).total <= 160u * 1024u;
 }

@@ -6,7 +6,7 @@
 // mixed batch (BASELINE config 3: 288..6912 bits) run like a uniform one.  The order is not
 // stable - it does not have to be: every descriptor carries its own symbol/output offsets, so no
 // output byte depends on the order.  Descriptors the launch was not sized for (framebits above
-// max_framebits or not a multiple of 8) sort to the end and are skipped by the decoder as before.
+// max_framebits or odd) sort to the end and are skipped by the decoder as before.
 //
 // Three small kernels on the caller's stream: histogram, descending exclusive scan, scatter.
 // Histogram and scatter privatise the bins in LDS (one global atomic per workgroup and length),
@@ -21,7 +21,7 @@ constexpr u32 TPB = 1024;
 
 __device__ __forceinline__ u32 key_of(const vit_frame_desc& d, u32 maxfb) {
     const u32 fb = d.framebits;
-    return (fb <= maxfb && (fb & 7u) == 0) ? (fb >> 3) : 0u;
+    return (fb <= maxfb && (fb & 1u) == 0) ? ((fb + 7u) >> 3) : 0u;
 }
 
 __global__ __launch_bounds__(TPB) void desc_hist_kernel(const vit_frame_desc* __restrict__ desc, long long n, u32 maxfb,

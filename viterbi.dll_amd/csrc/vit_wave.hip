@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64) void vit_wave_kernel(const uint8_t* __restrict_
             if (framebits > max_framebits) continue;  // the launch's LDS was not sized for it: skipped
         } else {
             sym_off = (size_t)f * 4u * (framebits + VIT_TAIL);
-            out_off = (size_t)f * (framebits >> 3);
+            out_off = (size_t)f * ((framebits + 7u) >> 3);
         }
         const uint32_t T = ((framebits + VIT_TAIL) >> 1) << 1;  // deconvolve.cpp:126: 2 steps per iteration
         const uint32_t* s32 = reinterpret_cast<const uint32_t*>(sym + sym_off);

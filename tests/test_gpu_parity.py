@@ -242,7 +242,7 @@ def test_varlen_device_sort_mixed_and_invalid(V, O, torch_cuda):
         if i not in (bad_long, bad_odd):
             want[oo:oo + fb // 8] = O.decode_batch(fb, sym[so:so + O.sym_len(fb)])[0]
     desc["framebits"][bad_long] = 9216 + 8   # beyond max_framebits
-    desc["framebits"][bad_odd] = fbs[bad_odd] + 4  # not a multiple of 8
+    desc["framebits"][bad_odd] = fbs[bad_odd] + 1  # odd: not a valid frame length
     d_desc = torch.from_numpy(desc.view(np.uint8)).cuda()
     d_out = torch.full((out_bytes,), 0x5A, dtype=torch.uint8, device="cuda")
     V.decode_varlen_dev(torch.from_numpy(sym).cuda(), d_out, d_desc, len(fbs), 9216)

@@ -198,12 +198,12 @@ def test_golden_fixtures(O):
 
 
 def test_packed_layout_emulation(O):
-    """CPU-only check of the packed kernel's index math (tools/emulate_pk.py): rotating lane<->state
+    """CPU-only check of the packed kernel's index math (tests/tools/emulate_pk.py): rotating lane<->state
     map, table triples, decision-history layout and the traceback position formula, emulated lane by
     lane in numpy, must reproduce the oracle."""
     import importlib.util
     spec = importlib.util.spec_from_file_location(
-        "emulate_pk", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "emulate_pk.py"))
+        "emulate_pk", os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "emulate_pk.py"))
     emu = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(emu)
     for fb in (40, 136):

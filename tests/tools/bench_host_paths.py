@@ -2,7 +2,7 @@
 """PCIe-inclusive rates of the host-buffer entry points (never the headline value)."""
 import json, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import _vitpkg
 V = _vitpkg.load_package(); O = _vitpkg.load_oracle(); V.initialize(); V.WakeUpYMM()
 fb = 768

@@ -2,7 +2,7 @@
 """RS(120,110) batch micro-benchmark (config 5's second stage)."""
 import json, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import _vitpkg
 V = _vitpkg.load_package(); O = _vitpkg.load_oracle(); V.initialize()
 dev = torch.device("cuda", 0)

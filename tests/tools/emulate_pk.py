@@ -5,14 +5,14 @@ format; today it stores M only and splits the pre-pass differently, same values)
 with the rotating lane<->state map, u16 biased arithmetic, renormalisation, the decision-history
 layout, and a serial traceback through that layout with the physical position formula
 l = ror5(state>>1, t mod 5).  Compares the decoded bytes with the oracle; also run by
-tests/test_oracle_kat.py::test_packed_layout_emulation.  Run: python tools/emulate_pk.py [framebits]
+tests/test_oracle_kat.py::test_packed_layout_emulation.  Run: python tests/tools/emulate_pk.py [framebits]
 """
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import _vitpkg  # noqa: E402
 
 O = _vitpkg.load_oracle()

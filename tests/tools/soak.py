@@ -2,7 +2,7 @@
 """One-off soak: many frames, GPU (auto kernel) vs the CPU oracle, bit-exact.  Run on the GPU box."""
 import json, os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import _vitpkg
 from bench import make_frames
 V = _vitpkg.load_package(); O = _vitpkg.load_oracle(); V.initialize()

@@ -19,14 +19,14 @@ with open(os.path.join(dst, "%s_other_configs.jsonl" % tag), "w") as f:
                 f.write(line)
 shutil.copy(os.path.join(src, "vitbench.txt"), os.path.join(dst, "%s_vitbench.txt" % tag))
 with open(os.path.join(dst, "%s_soak.txt" % tag), "w") as f:
-    f.write("# tools/soak.py on MI355X: GPU (auto kernel) vs CPU oracle, bit-exact compare of every output byte\n"
+    f.write("# tests/tools/soak.py on MI355X: GPU (auto kernel) vs CPU oracle, bit-exact compare of every output byte\n"
             "# decode: lengths 768/288/1536/3072/6912/9216/776/784 x {Eb/N0 3 dB, 0 dB, 12 dB, uniform random bytes, saturation/renormalisation stress patterns};\n"
             "# RS: random superframes with 0..8 symbol errors per column, RSDims 24/12/5/1/37/256/300\n")
     for line in open(os.path.join(src, "soak.jsonl")):
         if "total_frames" in line or "rs_superframes" in line or '"rsdims"' in line:
             f.write(line)
 
-out = ["# %s - rocprofv3 --kernel-trace --stats -- python3 tools/bench_configs.py  (this repo's kernels only)\n" % tag]
+out = ["# %s - rocprofv3 --kernel-trace --stats -- python3 tests/tools/bench_configs.py  (this repo's kernels only)\n" % tag]
 for r in csv.DictReader(open(os.path.join(src, "kernel_stats.csv"))):
     if any(k in r["Name"] for k in OURS):
         out.append("%-64.64s calls=%-4s avg_us=%9.1f min_us=%9.1f max_us=%9.1f\n" % (

@@ -74,6 +74,12 @@ std::atomic<int> g_fault{0};   // reference: exceptCounter / decon_savemode
 std::atomic<int> g_kernel{0};  // 0 auto, 1 wave, 2 packed
 
 void probe_devices() {
+    // Callers are threads (README.md:56), each with its own stream.  ROCclr multiplexes a process's streams
+    // onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels that share a queue run one after the
+    // other: with the default, 16 concurrent deconvolve() callers get 41 k calls/s, with 16 queues 51 k, with
+    // 4 callers 24 k vs 40 k (profiles/r01_vitbench.txt).  Only effective if this is the process's first HIP
+    // call, and never overrides a value the user has set.
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
         (void)hipGetLastError();

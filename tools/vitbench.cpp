@@ -139,6 +139,17 @@ int main(int argc, char** argv) {
         for (int k = 0; k < 6; k++) p[5 + rs * pos[k]] = val[k];
         const int r2 = rscheck(p.data(), 0, rs, o.data());
         printf("RScheckSuperframe: 3 flipped bytes -> %d (nonzero out bytes %d), 6 errors in a column -> %d\n", r1, nz, r2);
+        // per-call time of the drop-in export (the reference runs it once per 5 audio frames)
+        for (unsigned rsd : {12u, 24u}) {
+            std::vector<unsigned char> q(120 * rsd, 0), oo(110 * rsd, 0);
+            q[7] = 0x21;
+            for (int i = 0; i < 50; i++) rscheck(q.data(), 0, rsd, oo.data());
+            const auto t0 = std::chrono::steady_clock::now();
+            const int reps = 1000;
+            for (int i = 0; i < reps; i++) rscheck(q.data(), 0, rsd, oo.data());
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+            printf("RScheckSuperframe RSDims %2u: %.1f us/call\n", rsd, us);
+        }
     }
     // 5. batched host entry point
     {

@@ -587,16 +587,35 @@ int RScheckSuperframe(unsigned char* p, int startIx, unsigned int RSDims, unsign
 static int rscheck_impl(unsigned char* p, unsigned int RSDims, unsigned char* outVector) {
     if (RSDims == 0) return 0;
     if (g_fault.load()) return -1;
-    if (!p || !outVector) {
-        set_err("RScheckSuperframe: NULL buffer");
+    if (!p || !outVector || RSDims > 65535u) {
+        set_err("RScheckSuperframe: bad arguments");
         return -1;
     }
-    int32_t ret = -1;
-    if (vit_rs_batch_host(p, outVector, &ret, RSDims, 1) != VIT_OK) {
+    // Zero-copy like deconvolve(): the 120*RSDims input bytes, the caller's current output bytes (columns at
+    // and after the first failure must keep them) and the return value live in the thread's mapped pinned
+    // buffer; the kernel reads and writes host memory directly - one launch, one sync, no hipMemcpy.
+    if (ctx_prepare() != VIT_OK) return -1;
+    const size_t in_sz = 120u * (size_t)RSDims, out_sz = 110u * (size_t)RSDims;
+    const size_t in_pad = (in_sz + 15u) & ~(size_t)15u, out_pad = (out_sz + 15u) & ~(size_t)15u;
+    if (grow_pin(in_pad + out_pad + 64) != VIT_OK) {
         g_fault.store(1);
         return -1;
     }
-    return ret;
+    unsigned char* h = (unsigned char*)t_ctx.h_pin;
+    unsigned char* d = (unsigned char*)t_ctx.h_pin_dev;
+    memcpy(h, p, in_sz);
+    memcpy(h + in_pad, outVector, out_sz);
+    int32_t* h_ret = reinterpret_cast<int32_t*>(h + in_pad + out_pad);
+    *h_ret = -1;
+    hipError_t e = rs_launch(d, d + in_pad, reinterpret_cast<int32_t*>(d + in_pad + out_pad), RSDims, 1, t_ctx.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(t_ctx.stream);
+    if (e != hipSuccess) {
+        set_err("RScheckSuperframe: %s", hipGetErrorString(e));
+        g_fault.store(1);
+        return -1;
+    }
+    memcpy(outVector, h + in_pad, out_sz);
+    return *h_ret;
 }
 
 int RSCheckSuperframe(unsigned char* p, int startIx, unsigned int RSDims, unsigned char* outVector) {

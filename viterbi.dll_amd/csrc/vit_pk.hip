@@ -400,7 +400,7 @@ DEV
 __device__ __attribute__((noinline))
 #endif
 u32 traceback_part(const char* dec, u32* scratch, u32* img, u32 fstride, u32 lane, u32 ts, u32 te, u32 te_max,
-                       u32 slot0, u32 P_top) {
+                       u32 slot0, u32 P_top, u32 dmask = 0xFFFFFFFFu) {
 #ifdef VIT_DIAG_NO_TB
     return P_top;  // timing-only diagnostic build: outputs are wrong
 #endif
@@ -448,8 +448,8 @@ u32 traceback_part(const char* dec, u32* scratch, u32* img, u32 fstride, u32 lan
             const u32 b0 = tbase - VIT_TAIL + lo;
             const u32 d = b0 >> 5, sft = b0 & 31u;
             if (val) {
-                atomicOr(&img[fi * fstride + d], val << sft);
-                if (sft) atomicOr(&img[fi * fstride + d + 1], val >> (32u - sft));
+                atomicOr(&img[fi * fstride + (d & dmask)], val << sft);  // dmask: the long-frame kernel's image is a ring
+                if (sft) atomicOr(&img[fi * fstride + ((d + 1u) & dmask)], val >> (32u - sft));
             }
         }
     }
@@ -627,15 +627,17 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
 // table is consumed longest-first.
 constexpr u32 LONG_LDS_BLOCKS = DUMP_GROUP + 1u;  // 17
 
+constexpr u32 IMG_RING = 16;  // output bit image of the long-frame kernel: a ring of 16 words (512 bits) per frame
+
 __host__ __device__ inline PkLayout pk_layout_long(u32 maxfb) {
     PkLayout l;
     l.maxfb = maxfb;
     l.dec_bytes = DUMP_GROUP * DEC_BLOCK;
-    const u32 scratch = 64u * 4u * pk_scratch_words(maxfb), img = 16u * pk_img_stride(maxfb);
+    const u32 scratch = 64u * 4u * pk_scratch_words(maxfb), img = 4u * 4u * IMG_RING;
     u32 tabregion = DEC_BLOCK + scratch + img;
     tabregion = tabregion > (u32)TAB_BYTES ? ((tabregion + 15u) & ~15u) : (u32)TAB_BYTES;
     l.img_off = l.dec_bytes + DEC_BLOCK + scratch;
-    l.total = l.dec_bytes + tabregion;
+    l.total = l.dec_bytes + tabregion;  // 10 KB for every length: 16 waves per CU
     return l;
 }
 
@@ -704,7 +706,6 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
         if (maxfb == 0) continue;
         const u32 nblk = (maxfb + VIT_TAIL + 15u) >> 4;
         const u32 G = nblk > LONG_LDS_BLOCKS ? nblk - LONG_LDS_BLOCKS : 0u;  // spilled blocks (<= spill_blocks)
-        const u32 fstride = pk_img_stride(maxfb);
         const u32 T_max = maxfb + VIT_TAIL;
         const u32 a_fb = pp ? fbits[2] : fbits[0], b_fb = pp ? fbits[3] : fbits[1];
         const u32 a_T = a_fb ? a_fb + VIT_TAIL : 0u, b_T = b_fb ? b_fb + VIT_TAIL : 0u;
@@ -741,16 +742,43 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
             }
         }
         __syncthreads();
-        for (u32 i = lane; i < 4u * fstride; i += 64u) img[i] = 0;
+        img[lane] = 0;  // 4 frames x IMG_RING words (the ring aliases the dead table region)
 
         // ---- traceback: LDS tail, then the spilled blocks 16 at a time from the top ----
-        const u32 fi = lane >> 4;
+        const u32 fi = lane >> 4, slot = lane & (IMG_RING - 1u);
         const u32 t_fb = fi == 0 ? fbits[0] : fi == 1 ? fbits[1] : fi == 2 ? fbits[2] : fbits[3];
         const u32 t_T = t_fb ? t_fb + VIT_TAIL : 0u;
+        uint8_t* o_f = out + (fi == 0 ? ooff[0] : fi == 1 ? ooff[1] : fi == 2 ? ooff[2] : ooff[3]);
+        const u32 nbytes_f = (t_fb + 7u) >> 3;  // a partial last byte is padded with zero bits (ChainBack starts from E = 0)
+        const bool o_aligned = (reinterpret_cast<uintptr_t>(o_f) & 3u) == 0;
+        u32 d_hi = (t_fb + 31u) >> 5;  // image words [d_lo, d_hi) of this lane's frame are not written out yet
+        // The image is a ring: after a part has been traced back, every decoded bit from its first step up is
+        // final.  Lane (frame, slot) owns the one word of [d_lo, d_hi) that maps to its ring slot: it goes out as
+        // 4 MSB-first bytes (deconvolve.cpp:432-433) and the slot is cleared for the words further down.
+        auto flush = [&](const u32 ts_done) {
+            const u32 d_lo = ts_done <= VIT_TAIL ? 0u : (ts_done - VIT_TAIL + 31u) >> 5;
+            __syncthreads();  // all atomicOr of the part have landed
+            const u32 d = d_lo + ((slot - d_lo) & (IMG_RING - 1u));
+            if (d < d_hi) {
+                const u32 v = __builtin_bswap32(__builtin_bitreverse32(img[lane]));  // byte k = bit-reversed byte k
+                img[lane] = 0;
+                const u32 b = 4u * d;
+                if (o_aligned && b + 4u <= nbytes_f) {
+                    *reinterpret_cast<u32*>(o_f + b) = v;
+                } else {
+#pragma unroll
+                    for (u32 k = 0; k < 4u; k++)
+                        if (b + k < nbytes_f) o_f[b + k] = (uint8_t)(v >> (8u * k));
+                }
+            }
+            d_hi = d_hi < d_lo ? d_hi : d_lo;
+            __syncthreads();
+        };
         u32* scratch = reinterpret_cast<u32*>(tab + DEC_BLOCK) + lane * pk_scratch_words(lay.maxfb);
         const u32 t_lo = G * 16u;
-        u32 P_part = traceback_part(dec, scratch, img, fstride, lane, t_lo > VIT_TAIL ? t_lo : VIT_TAIL, t_T, T_max, G,
-                                    P_ZERO);
+        const u32 ts_top = t_lo > VIT_TAIL ? t_lo : VIT_TAIL;
+        u32 P_part = traceback_part(dec, scratch, img, IMG_RING, lane, ts_top, t_T, T_max, G, P_ZERO, IMG_RING - 1u);
+        flush(ts_top);
         for (u32 g1 = G; g1 > 0;) {
             const u32 g0 = g1 > DUMP_GROUP ? g1 - DUMP_GROUP : 0u;
             uint2 d[DUMP_GROUP];
@@ -765,25 +793,9 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
             const u32 tsg = g0 ? g0 * 16u : VIT_TAIL, tend = g1 * 16u;
             const u32 te = t_T < tend ? t_T : tend, te_max = T_max < tend ? T_max : tend;
             const u32 P_top = t_T > tend ? P_part : P_ZERO;
-            P_part = traceback_part(dec, scratch, img, fstride, lane, tsg, te, te_max, g0, P_top);
+            P_part = traceback_part(dec, scratch, img, IMG_RING, lane, tsg, te, te_max, g0, P_top, IMG_RING - 1u);
+            flush(tsg);
             g1 = g0;
-        }
-        __syncthreads();
-
-        // ---- output bytes, MSB first (deconvolve.cpp:432-433) ----
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const u32 nbytes = (fbits[k] + 7u) >> 3;  // a partial last byte is padded with zero bits (ChainBack starts from E = 0)
-            uint8_t* o = out + ooff[k];
-            if (((ooff[k] | nbytes) & 3u) == 0) {
-                for (u32 m = lane; m < (nbytes >> 2); m += 64u)
-                    reinterpret_cast<u32*>(o)[m] = __builtin_bswap32(__builtin_bitreverse32(img[k * fstride + m]));
-            } else {
-                for (u32 j = lane; j < nbytes; j += 64u) {
-                    const u32 byte = (img[k * fstride + (j >> 2)] >> (8u * (j & 3u))) & 0xFFu;
-                    o[j] = (uint8_t)(__builtin_bitreverse32(byte) >> 24);
-                }
-            }
         }
         __syncthreads();  // the image is read before the next group's pre-pass reuses the region
     }

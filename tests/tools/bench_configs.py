@@ -20,7 +20,12 @@ dev = torch.device("cuda", 0)
 V.initialize()
 
 
-def timeit(fn, steps=10, warm=2):
+def timeit(fn, steps=10, warm=2, prewarm_ms=60.0):
+    # the GPU needs ~15 ms of sustained load to reach steady-state clocks (tools/exp/trend.py): untimed pre-conditioning
+    t_end = time.perf_counter() + prewarm_ms / 1e3
+    while time.perf_counter() < t_end:
+        fn()
+        torch.cuda.synchronize()
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -60,7 +65,7 @@ for label in ("as drawn", "vit_sort_descs"):
     out = torch.zeros(out_bytes, dtype=torch.uint8, device=dev)
     d_desc = torch.from_numpy(desc.view(np.uint8)).to(dev)
     mx = int(f.max())
-    ms = timeit(lambda: V.decode_varlen_dev(sym, out, d_desc, n, mx), steps=5, warm=1)
+    ms = timeit(lambda: V.decode_varlen_dev(sym, out, d_desc, n, mx), steps=10, warm=5)
     # parity on a sample of frames
     idx = rng.choice(n, 64, replace=False)
     sh, oh = sym.cpu().numpy(), out.cpu().numpy()
@@ -114,8 +119,9 @@ for rsdims in (24, 12):
     d_work = torch.zeros((nsf, 120 * rsdims), dtype=torch.uint8, device=dev)
     d_out = torch.zeros((nsf, 110 * rsdims), dtype=torch.uint8, device=dev)
     d_ret = torch.zeros(nsf, dtype=torch.int32, device=dev)
-    ms = timeit(lambda: V.dabplus_superframes_dev(sym, d_work, d_out, d_ret, rsdims, nsf), steps=5, warm=1)
-    ms_dec = timeit(lambda: V.decode_batch_dev(sym, d_work, fb, nsf * 5), steps=5, warm=1)
+    # (the first ~10 launches on a fresh 1.5 GB input + 2.9 GB spill buffer run up to 20 % slower: warm up first)
+    ms = timeit(lambda: V.dabplus_superframes_dev(sym, d_work, d_out, d_ret, rsdims, nsf), steps=10, warm=2)
+    ms_dec = timeit(lambda: V.decode_batch_dev(sym, d_work, fb, nsf * 5), steps=10, warm=2)
     k = 32  # parity of both stages on a sample of superframes
     dec_ref = O.decode_batch(fb, sym[:5 * k].cpu().numpy(), nthreads=16).reshape(k, 120 * rsdims)
     ret_ref, out_ref = O.rs_check_batch(dec_ref, rsdims)

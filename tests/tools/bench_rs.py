@@ -23,8 +23,10 @@ p = p.reshape(base_n, -1)
 ret_ref, out_ref = O.rs_check_batch(p, rsdims)
 d_p = torch.from_numpy(p).to(dev).repeat(nsf // base_n, 1).contiguous()
 d_out = torch.zeros((nsf, 110 * rsdims), dtype=torch.uint8, device=dev); d_ret = torch.zeros(nsf, dtype=torch.int32, device=dev)
-for _ in range(2): V.rs_batch_dev(d_p, d_out, d_ret, rsdims, nsf)
-torch.cuda.synchronize()
+import time as _t
+_te = _t.perf_counter() + 0.06  # clock pre-conditioning, untimed
+while _t.perf_counter() < _te:
+    V.rs_batch_dev(d_p, d_out, d_ret, rsdims, nsf); torch.cuda.synchronize()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record()
 for _ in range(10): V.rs_batch_dev(d_p, d_out, d_ret, rsdims, nsf)

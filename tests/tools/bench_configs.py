@@ -65,7 +65,7 @@ for label in ("as drawn", "vit_sort_descs"):
     out = torch.zeros(out_bytes, dtype=torch.uint8, device=dev)
     d_desc = torch.from_numpy(desc.view(np.uint8)).to(dev)
     mx = int(f.max())
-    ms = timeit(lambda: V.decode_varlen_dev(sym, out, d_desc, n, mx), steps=10, warm=5)
+    ms = timeit(lambda: V.decode_varlen_dev(sym, out, d_desc, n, mx), steps=10, warm=2, prewarm_ms=200.0)
     # parity on a sample of frames
     idx = rng.choice(n, 64, replace=False)
     sh, oh = sym.cpu().numpy(), out.cpu().numpy()
@@ -120,8 +120,9 @@ for rsdims in (24, 12):
     d_out = torch.zeros((nsf, 110 * rsdims), dtype=torch.uint8, device=dev)
     d_ret = torch.zeros(nsf, dtype=torch.int32, device=dev)
     # (the first ~10 launches on a fresh 1.5 GB input + 2.9 GB spill buffer run up to 20 % slower: warm up first)
-    ms = timeit(lambda: V.dabplus_superframes_dev(sym, d_work, d_out, d_ret, rsdims, nsf), steps=10, warm=2)
-    ms_dec = timeit(lambda: V.decode_batch_dev(sym, d_work, fb, nsf * 5), steps=10, warm=2)
+    ms_dec = timeit(lambda: V.decode_batch_dev(sym, d_work, fb, nsf * 5), steps=10, warm=2, prewarm_ms=300.0)
+    ms = timeit(lambda: V.dabplus_superframes_dev(sym, d_work, d_out, d_ret, rsdims, nsf), steps=10, warm=2, prewarm_ms=100.0)
+    ms_rs = timeit(lambda: V.rs_batch_dev(d_work, d_out, d_ret, rsdims, nsf), steps=10, warm=2)
     k = 32  # parity of both stages on a sample of superframes
     dec_ref = O.decode_batch(fb, sym[:5 * k].cpu().numpy(), nthreads=16).reshape(k, 120 * rsdims)
     ret_ref, out_ref = O.rs_check_batch(dec_ref, rsdims)
@@ -129,7 +130,7 @@ for rsdims in (24, 12):
         and bool(np.array_equal(d_out[:k].cpu().numpy()[ret_ref >= 0], out_ref[ret_ref >= 0]))
     ret = d_ret.cpu().numpy()
     print(json.dumps({"case": "config5 pipeline decode x5 + RS", "rsdims": rsdims, "superframes": nsf, "framebits": fb,
-                      "ms": round(ms, 3), "ms_decode_only": round(ms_dec, 3),
+                      "ms": round(ms, 3), "ms_decode_only": round(ms_dec, 3), "ms_rs_only": round(ms_rs, 3),
                       "superframes_per_s": round(nsf / ms * 1e3), "decoded_Mbit_s": round(nsf * 5 * fb / ms / 1e3, 1),
                       "superframes_failed": int((ret < 0).sum()), "symbols_corrected": int(ret[ret > 0].sum()),
                       "parity_sample_ok": ok}), flush=True)

@@ -35,7 +35,7 @@ for r in rows[:6]:
 
 tot = {}
 meta = {}
-for p in ("p1", "p2", "p3"):
+for p in ("p1", "p2", "p3", "p4"):
     fn = os.path.join(src, "pmc_%s.csv" % p)
     if not os.path.exists(fn):
         continue
@@ -71,6 +71,10 @@ if "SQ_ACTIVE_INST_VALU" in tot and "GRBM_GUI_ACTIVE" in tot:
     valu_busy = tot["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * kernel_cycles)
     lines.append("kernel cycles %.4g (clock %.2f GHz); VALU busy = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * cycles) = %.1f %%\n"
                  % (kernel_cycles, kernel_cycles / (avg_ns or 1) , 100.0 * valu_busy))
+if "SQ_LDS_BANK_CONFLICT" in tot and "SQ_LDS_IDX_ACTIVE" in tot and tot["SQ_LDS_IDX_ACTIVE"]:
+    lines.append("LDS: bank-conflict cycles / index-active cycles = %.1f %%; LDS-instruction busy = SQ_ACTIVE_INST_LDS*4 / (256 CUs * cycles) = %.1f %%\n" % (
+        100.0 * tot["SQ_LDS_BANK_CONFLICT"] / tot["SQ_LDS_IDX_ACTIVE"],
+        100.0 * tot.get("SQ_ACTIVE_INST_LDS", 0) * 4.0 / (256.0 * (tot.get("GRBM_GUI_ACTIVE", 0) / 8.0 or 1))))
 if "SQ_WAVES" in tot:
     w = tot["SQ_WAVES"]
     lines.append("per wave: VALU %.0f  SALU %.0f  LDS %.0f  wave-cycles(quad) %.0f\n" % (

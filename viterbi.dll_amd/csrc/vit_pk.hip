@@ -260,17 +260,31 @@ DEV void prepass(u32 sa, u32 sb, char* tab, u32 lane, const u32 (&sel)[4]) {
                         __builtin_amdgcn_perm(bhi, ahi, sel[2]), __builtin_amdgcn_perm(bhi, ahi, sel[3]));
 }
 
-// The 4 soft symbols of step t of one frame as 4 bytes.  SYM32 = the reference ABI's format (one u32 per
-// symbol, low byte used: deconvolve.cpp:158-165) read straight from memory - the ingest narrowing fused
-// into the pre-pass (16 B per step instead of 4, no intermediate u8 buffer).
+// The 4 soft symbols of step t of one frame.  SYM32 = the reference ABI's format (one u32 per symbol, low
+// byte used: deconvolve.cpp:158-165) read straight from memory - the ingest narrowing fused into the
+// pre-pass (16 B per step instead of 4, no intermediate u8 buffer).  The load returns the RAW words and the
+// narrowing happens where the symbols are consumed, 32 steps later: packing right after the load would
+// make the wave wait for HBM at every pre-pass.
 template <bool SYM32>
-DEV u32 load_step(const uint8_t* frame, u32 t) {
+struct RawStep {
+    typedef u32 type;
+};
+template <>
+struct RawStep<true> {
+    typedef uint4 type;
+};
+template <bool SYM32>
+DEV typename RawStep<SYM32>::type load_step(const uint8_t* frame, u32 t, bool valid) {
+    typedef typename RawStep<SYM32>::type T;
     if constexpr (!SYM32) {
-        return reinterpret_cast<const u32*>(frame)[t];
+        return valid ? reinterpret_cast<const T*>(frame)[t] : 0u;
     } else {
-        const uint4 v = reinterpret_cast<const uint4*>(frame)[t];
-        return __builtin_amdgcn_perm(v.y, v.x, 0x0C0C0400u) | __builtin_amdgcn_perm(v.w, v.z, 0x04000C0Cu);
+        return valid ? reinterpret_cast<const T*>(frame)[t] : make_uint4(0u, 0u, 0u, 0u);
     }
+}
+DEV u32 pack_step(u32 raw) { return raw; }
+DEV u32 pack_step(const uint4& v) {
+    return __builtin_amdgcn_perm(v.y, v.x, 0x0C0C0400u) | __builtin_amdgcn_perm(v.w, v.z, 0x04000C0Cu);
 }
 
 typedef u32 v32u __attribute__((ext_vector_type(32)));
@@ -544,15 +558,15 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
 
     // ---- ACS over the blocks ----
     {
-        u32 sa = tau < a_T ? load_step<SYM32>(a_sym, tau) : 0u, sb = tau < b_T ? load_step<SYM32>(b_sym, tau) : 0u;
+        auto sa = load_step<SYM32>(a_sym, tau, tau < a_T), sb = load_step<SYM32>(b_sym, tau, tau < b_T);
         u32 v = 0;
         for (u32 rb = 0; rb < nb; rb++) {
             if ((rb & 1u) == 0) {
                 __syncthreads();  // every lane is done with the previous table
-                prepass(sa, sb, tab, lane, sel);
+                prepass(pack_step(sa), pack_step(sb), tab, lane, sel);
                 const u32 tn = (rb + 2u) * 16u + tau;
-                sa = tn < a_T ? load_step<SYM32>(a_sym, tn) : 0u;  // prefetch the next 32 steps' symbols
-                sb = tn < b_T ? load_step<SYM32>(b_sym, tn) : 0u;
+                sa = load_step<SYM32>(a_sym, tn, tn < a_T);  // prefetch the next 32 steps' symbols
+                sb = load_step<SYM32>(b_sym, tn, tn < b_T);
                 __syncthreads();
             }
             if (VIT_STEPS6 && rb + 1u == nb && (T_max & 15u) == 6u)
@@ -717,15 +731,15 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
         u32 A = l5 == 0 ? 0u : 0x003F003Fu, B = 0x003F003Fu;
         u32 acc0 = 0, acc1 = 0;
         {
-            u32 sa = tau < a_T ? load_step<SYM32>(a_sym, tau) : 0u, sb = tau < b_T ? load_step<SYM32>(b_sym, tau) : 0u;
+            auto sa = load_step<SYM32>(a_sym, tau, tau < a_T), sb = load_step<SYM32>(b_sym, tau, tau < b_T);
             u32 v = 0;
             for (u32 rb = 0; rb < nblk; rb++) {
                 if ((rb & 1u) == 0) {
                     __syncthreads();
-                    prepass(sa, sb, tab, lane, sel);
+                    prepass(pack_step(sa), pack_step(sb), tab, lane, sel);
                     const u32 tn = (rb + 2u) * 16u + tau;
-                    sa = tn < a_T ? load_step<SYM32>(a_sym, tn) : 0u;
-                    sb = tn < b_T ? load_step<SYM32>(b_sym, tn) : 0u;
+                    sa = load_step<SYM32>(a_sym, tn, tn < a_T);
+                    sb = load_step<SYM32>(b_sym, tn, tn < b_T);
                     __syncthreads();
                 }
                 if (VIT_STEPS6 && rb + 1u == nblk && (T_max & 15u) == 6u)

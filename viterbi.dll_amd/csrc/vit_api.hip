@@ -498,21 +498,19 @@ static int deconvolve_impl(unsigned int framebits, unsigned int* symbols, unsign
         g_fault.store(1);
         return 1;
     };
-    // Zero-copy staging: the pinned buffer is mapped into the device's address space.  The ingest kernel
-    // pulls the caller's u32 symbols out of host memory in one wide pass (12 KB over PCIe, all loads in
-    // flight at once) and the decode kernel writes its framebits/8 bytes straight back: no hipMemcpy round
-    // trips, two launches, one sync.  (Letting the decode kernel read the u32 symbols from host memory
-    // itself was measured slower: its pre-pass would pay the PCIe latency once per 32 steps: 109 vs 82 us.)
-    hipError_t e;
+    // Zero-copy staging: the pinned buffer is mapped into the device's address space.  The decode kernel reads
+    // the caller's u32 symbols straight from host memory (12 KB over PCIe; its pre-pass loads run 32 steps
+    // ahead of their use, which covers the PCIe latency) and writes its (framebits+7)/8 bytes straight back:
+    // no hipMemcpy round trips, ONE launch, one sync.  (With the wave-per-frame kernel selected the ingest
+    // kernel narrows the symbols first.)
     unsigned char* h_out = (unsigned char*)t_ctx.h_pin + nsym * 4;
     memcpy(t_ctx.h_pin, symbols, nsym * 4);
-    if ((e = vit_launch_pack((const uint32_t*)t_ctx.h_pin_dev, (uint8_t*)t_ctx.d_sym8, (int64_t)nsym, t_ctx.stream)) != hipSuccess)
-        return fail("pack", e);
-    if (launch_decode((const uint8_t*)t_ctx.d_sym8, (uint8_t*)t_ctx.h_pin_dev + nsym * 4, nullptr, framebits, framebits, 1,
-                      t_ctx.stream) != VIT_OK) {
+    if (launch_decode_u32((const uint32_t*)t_ctx.h_pin_dev, (uint8_t*)t_ctx.d_sym8, (uint8_t*)t_ctx.h_pin_dev + nsym * 4,
+                          nullptr, framebits, framebits, 1, (int64_t)nsym, t_ctx.stream) != VIT_OK) {
         g_fault.store(1);
         return 1;
     }
+    hipError_t e;
     if ((e = hipStreamSynchronize(t_ctx.stream)) != hipSuccess) return fail("sync", e);
     memcpy(decodedBits, h_out, out_sz);
     return 0;

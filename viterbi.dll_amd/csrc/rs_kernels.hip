@@ -370,7 +370,8 @@ __device__ __forceinline__ void copy_linear(uint8_t* dst, const uint8_t* src, ui
 }
 
 // rsdims <= 256: spb = 256/rsdims superframes per pass, natural layout in LDS (see the header comment).
-__global__ __launch_bounds__(RS_THREADS) void rs_kernel(const uint8_t* __restrict__ p, uint8_t* __restrict__ out,
+// (second launch bound: 4 waves per SIMD = 4 workgroups per CU, which is what the 40 KB of LDS allow)
+__global__ __launch_bounds__(RS_THREADS, 4) void rs_kernel(const uint8_t* __restrict__ p, uint8_t* __restrict__ out,
                                                         int32_t* __restrict__ ret, uint32_t rsdims,
                                                         long long nsf) {
     __shared__ __attribute__((aligned(16))) uint8_t cw[NCW * RS_THREADS];  // [superframe][row][column]
@@ -393,6 +394,24 @@ __global__ __launch_bounds__(RS_THREADS) void rs_kernel(const uint8_t* __restric
     const uint32_t lsf = tid / rsdims, colidx = tid - lsf * rsdims;
     constexpr int NOFAIL = 0x7FFFFFFF;
 
+    // The next group's input block is fetched into registers (8-byte words, 15 per thread) while the current
+    // one is decoded, so the HBM latency of the load phase overlaps the LDS-bound decode of the same workgroup.
+    constexpr uint32_t PRE = NCW * RS_THREADS / 8u / RS_THREADS;  // 15
+    const bool pre_ok = (reinterpret_cast<uintptr_t>(p) & 7u) == 0;  // in_sz is a multiple of 8
+    uint2 pre[PRE];
+    auto prefetch = [&](long long gg) {
+        const long long s0 = gg * spb;
+        const uint32_t nl = nsf - s0 < (long long)spb ? (uint32_t)(nsf - s0) : spb;
+        const uint32_t nw = nl * in_sz / 8u;
+        const uint2* src = reinterpret_cast<const uint2*>(p + (size_t)s0 * in_sz);
+#pragma unroll
+        for (uint32_t k = 0; k < PRE; k++) {
+            const uint32_t i = tid + k * RS_THREADS;
+            pre[k] = i < nw ? src[i] : make_uint2(0u, 0u);
+        }
+    };
+    if (pre_ok && (long long)blockIdx.x < ngroups) prefetch(blockIdx.x);
+
     for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
         const long long sf0 = g * spb;
         const uint32_t nloc = nsf - sf0 < (long long)spb ? (uint32_t)(nsf - sf0) : spb;
@@ -400,7 +419,17 @@ __global__ __launch_bounds__(RS_THREADS) void rs_kernel(const uint8_t* __restric
             s_minfail[tid] = NOFAIL;
             s_sum[tid] = 0;
         }
-        copy_linear(cw, p + (size_t)sf0 * in_sz, nloc * in_sz, tid);
+        if (pre_ok) {
+            const uint32_t nw = nloc * in_sz / 8u;
+#pragma unroll
+            for (uint32_t k = 0; k < PRE; k++) {
+                const uint32_t i = tid + k * RS_THREADS;
+                if (i < nw) reinterpret_cast<uint2*>(cw)[i] = pre[k];
+            }
+            if (g + gridDim.x < ngroups) prefetch(g + gridDim.x);
+        } else {
+            copy_linear(cw, p + (size_t)sf0 * in_sz, nloc * in_sz, tid);
+        }
         __syncthreads();
         const bool active = lsf < nloc;
         int res = 0;
@@ -451,6 +480,14 @@ hipError_t rs_launch(const uint8_t* d_p, uint8_t* d_out, int32_t* d_ret, uint32_
     const uint32_t spb = rsdims <= RS_THREADS ? RS_THREADS / rsdims : 1u;
     long long groups = (nsf + spb - 1) / spb;
     if (groups > (1 << 20)) groups = 1 << 20;
+    if (rsdims <= RS_THREADS) {
+        // persistent workgroups (4 fit a CU): each walks its groups with the next input block already in flight
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            cus = 256;
+        const long long resident = 4LL * cus;
+        if (groups > resident) groups = resident;
+    }
     if (rsdims <= RS_THREADS)
         hipLaunchKernelGGL(rs_kernel, dim3((unsigned)groups), dim3(RS_THREADS), 0, stream, d_p, d_out, d_ret, rsdims,
                            (long long)nsf);

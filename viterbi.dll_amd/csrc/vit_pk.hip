@@ -791,19 +791,25 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
         u32* scratch = reinterpret_cast<u32*>(tab + DEC_BLOCK) + lane * pk_scratch_words(lay.maxfb);
         const u32 t_lo = G * 16u;
         const u32 ts_top = t_lo > VIT_TAIL ? t_lo : VIT_TAIL;
+        // the spilled blocks come back 16 at a time; a group is fetched into registers while the part above it
+        // is being traced back, so its HBM latency is off the wave's critical path
+        uint2 d[DUMP_GROUP];
+        auto fetch = [&](const u32 g0, const u32 g1) {
+#pragma unroll
+            for (u32 k = 0; k < DUMP_GROUP; k++)
+                d[k] = (g0 + k < g1) ? wspill[(size_t)(g0 + k) * 64u] : make_uint2(0u, 0u);
+        };
+        if (G) fetch(G > DUMP_GROUP ? G - DUMP_GROUP : 0u, G);
         u32 P_part = traceback_part(dec, scratch, img, IMG_RING, lane, ts_top, t_T, T_max, G, P_ZERO, IMG_RING - 1u);
         flush(ts_top);
         for (u32 g1 = G; g1 > 0;) {
             const u32 g0 = g1 > DUMP_GROUP ? g1 - DUMP_GROUP : 0u;
-            uint2 d[DUMP_GROUP];
-#pragma unroll
-            for (u32 k = 0; k < DUMP_GROUP; k++)
-                d[k] = (g0 + k < g1) ? wspill[(size_t)(g0 + k) * 64u] : make_uint2(0u, 0u);
             __syncthreads();
 #pragma unroll
             for (u32 k = 0; k < DUMP_GROUP; k++)
                 *reinterpret_cast<uint2*>(dec + k * DEC_BLOCK + lane * 8) = d[k];
             __syncthreads();
+            if (g0) fetch(g0 > DUMP_GROUP ? g0 - DUMP_GROUP : 0u, g0);  // next group down, in flight during this part
             const u32 tsg = g0 ? g0 * 16u : VIT_TAIL, tend = g1 * 16u;
             const u32 te = t_T < tend ? t_T : tend, te_max = T_max < tend ? T_max : tend;
             const u32 P_top = t_T > tend ? P_part : P_ZERO;

@@ -20,7 +20,7 @@ with open(os.path.join(dst, "%s_other_configs.jsonl" % tag), "w") as f:
 shutil.copy(os.path.join(src, "vitbench.txt"), os.path.join(dst, "%s_vitbench.txt" % tag))
 with open(os.path.join(dst, "%s_soak.txt" % tag), "w") as f:
     f.write("# tests/tools/soak.py on MI355X: GPU (auto kernel) vs CPU oracle, bit-exact compare of every output byte\n"
-            "# decode: lengths 768/288/1536/3072/6912/9216/776/784 x {Eb/N0 3 dB, 0 dB, 12 dB, uniform random bytes, saturation/renormalisation stress patterns};\n"
+            "# decode (5 seed sets): lengths 768/288/1536/3072/6912/9216/776/784/770/9214 x {Eb/N0 3 dB, 0 dB, 12 dB, uniform random bytes, saturation/renormalisation stress patterns};\n"
             "# RS: random superframes with 0..8 symbol errors per column, RSDims 24/12/5/1/37/256/300\n")
     for line in open(os.path.join(src, "soak.jsonl")):
         if "total_frames" in line or "rs_superframes" in line or '"rsdims"' in line:

@@ -875,7 +875,11 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
     const long long groups = (nframes + 3) / 4;
     if (groups > 0x7FFFFFFFLL) return hipErrorInvalidValue;
     const u32 nblk = (max_framebits + VIT_TAIL + 15u) >> 4;
+#ifdef VIT_FORCE_LONG
+    const bool is_long = true;  // experiment: every length through the persistent spill kernel
+#else
     const bool is_long = nblk > SEG_BLOCKS;
+#endif
     const bool sort = d_desc != nullptr && nframes >= SORT_MIN_FRAMES && sort_enabled();
     if (!is_long && !sort) {
         const PkLayout lay = pk_layout(max_framebits);

@@ -7,6 +7,10 @@ in the device format (1 byte per soft symbol).  N>1 = one process per GPU, every
 decodes its own 65536-frame shard (independent frames, no data-path collective: weak
 scaling); value = all ranks' decoded bits / max-over-ranks time.
 
+Launching: `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks
+itself (fresh child processes, created before this process has touched the GPU); under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it is one of the ranks.
+
 Prints ONE JSON line (rank 0).  `roofline` prices the decode kernel against the HBM
 peak with the ALGORITHMIC bytes (3192 B per FIC frame: 3096 symbol bytes in + 96 out);
 `cpu_baseline` is this repo's own AVX2 port of the same integer specification
@@ -15,6 +19,8 @@ peak with the ALGORITHMIC bytes (3192 B per FIC frame: 3096 symbol bytes in + 96
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -109,7 +115,7 @@ def cpu_baseline(O, sym_host, framebits, want_seconds=10.0):
     return base, ref
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -120,56 +126,133 @@ def main():
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
                     help="untimed GPU pre-conditioning before the W warm-up steps: the MI355X needs ~15 ms of sustained load "
                          "to reach its steady-state clocks (first launches run ~10 %% slower, tools/exp/trend.py)")
-    ap.add_argument("--mode", choices=["shard", "scatter"], default="shard",
-                    help="shard: every rank owns its frames (default, no collective); scatter: rank 0 owns all "
-                         "frames, round-robin RCCL scatter + decode + gather inside the timed step (config 4)")
-    args = ap.parse_args()
+    ap.add_argument("--mode", choices=["shard", "scatter", "scatter-plain"], default="shard",
+                    help="shard: every rank owns its frames (default, no collective); scatter: rank 0 owns all frames, "
+                         "chunked + overlapped RCCL send/recv pipeline inside the timed step (config 4, "
+                         "sharding.decode_stream); scatter-plain: ONE scatter + decode + ONE gather (f mod N)")
+    ap.add_argument("--chunk-frames", type=int, default=32768, help="scatter mode: frames per rank per chunk")
+    ap.add_argument("--root-frames", type=int, default=None,
+                    help="scatter mode: frames the root keeps per chunk (default = --chunk-frames)")
+    ap.add_argument("--spawn", action="store_true", help="start the ranks as child processes even for --gpus 1")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo + --stub: CPU rehearsal of the launcher and the collectives (tests)")
+    ap.add_argument("--stub", action="store_true",
+                    help="TEST ONLY: no GPU, the decoder is replaced by a byte-copy stand-in; the JSON line says so "
+                         "and its value is not a measurement")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args, argv):
+    """The bare `python bench.py --gpus N`: start N ranks (one per GPU) as fresh child processes.  Nothing in
+    this process has initialised HIP (importing torch does not), and it never will: it only waits.  The
+    children inherit stdout/stderr, so rank 0's JSON line is this command's JSON line."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env["MASTER_PORT"] = str(_free_port())
+    env["WORLD_SIZE"] = str(args.gpus)
+    env["VIT_BENCH_SPAWNED"] = "1"
+    procs = []
+    for r in range(args.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
+def stub_decode(sym_block, out_block):
+    """TEST ONLY stand-in for the decoder (CPU rehearsal): the first bytes of every frame's symbols"""
+    out_block.copy_(sym_block[:, :out_block.shape[1]])
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        rc = spawn_ranks(args, argv)
+        if rc:
+            sys.exit(rc)
+        return None
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    spawned = "WORLD_SIZE" in os.environ
     dist = None
-    if world > 1:
+    if spawned:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("VITERBI_AMD_DEVICE", str(local_rank))
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.stub:
+            dist.init_process_group(args.backend)
+        else:
+            os.environ.setdefault("VITERBI_AMD_DEVICE", str(local_rank))
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(args.backend, device_id=torch.device("cuda", local_rank))
+    elif not args.stub:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cpu") if args.stub else torch.device("cuda", local_rank if spawned else 0)
+    sync = (lambda: None) if args.stub else torch.cuda.synchronize
 
     V = _vitpkg.load_package()
-    assert V.device_count() >= 1, "libviterbi.so sees no gfx950 device: " + V.last_error()
-    V.initialize()
-    V.set_kernel(args.kernel)
+    if not args.stub:
+        assert V.device_count() >= 1, "libviterbi.so sees no gfx950 device: " + V.last_error()
+        V.initialize()
+        V.set_kernel(args.kernel)
 
     n = args.frames
+    out_len = (FRAMEBITS + 7) // 8
     d_sym = make_frames(n, FRAMEBITS, seed=1234 + rank, device=dev)
-    d_out = torch.zeros((n, FRAMEBITS // 8), dtype=torch.uint8, device=dev)
-    torch.cuda.synchronize()
+    d_out = torch.zeros((n, out_len), dtype=torch.uint8, device=dev)
+    sync()
 
-    if args.mode == "scatter" and dist:
+    def decode_into(sym_block, out_block):
+        if args.stub:
+            stub_decode(sym_block, out_block)
+        else:
+            V.decode_batch_dev(sym_block, out_block, FRAMEBITS, sym_block.shape[0])  # enqueues on torch's current stream
+
+    routing_ok = None
+    if args.mode != "shard" and dist:
         from importlib import import_module
         sharding = import_module("viterbi_dll_amd.sharding")
         n_total = n * world
         d_all = make_frames(n_total, FRAMEBITS, seed=99, device=dev) if rank == 0 else None
-        d_loc_out = torch.zeros((sharding.shard_count(n_total, rank, world), FRAMEBITS // 8), dtype=torch.uint8, device=dev)
+        d_all_out = torch.zeros((n_total, out_len), dtype=torch.uint8, device=dev) if rank == 0 else None
+        if args.mode == "scatter":
+            def step():
+                sharding.decode_stream(d_all, d_all_out, n_total, FRAMEBITS, decode_into, args.chunk_frames,
+                                       args.root_frames)
+        else:
+            d_loc_out = torch.zeros((sharding.shard_count(n_total, rank, world), out_len), dtype=torch.uint8, device=dev)
 
-        def _decode(local):
-            V.decode_batch_dev(local, d_loc_out, FRAMEBITS, local.shape[0])
-            return d_loc_out
+            def _decode(local):
+                decode_into(local, d_loc_out)
+                return d_loc_out
 
-        def step():
-            sharding.decode_sharded(d_all, n_total, FRAMEBITS, _decode)
+            def step():
+                full = sharding.decode_sharded(d_all, n_total, FRAMEBITS, _decode)
+                if rank == 0:
+                    d_all_out.copy_(full)
     else:
         def step():
-            V.decode_batch_dev(d_sym, d_out, FRAMEBITS, n)  # enqueues on torch's current stream
+            decode_into(d_sym, d_out)
 
     # clock pre-conditioning (untimed, part of set-up like allocation and module load): same launches as a step
-    if args.prewarm_ms > 0:
-        if args.mode == "scatter" and dist:
-            for _ in range(20):  # a fixed count keeps the ranks' collectives matched
+    if args.prewarm_ms > 0 and not args.stub:
+        if args.mode != "shard" and dist:
+            for _ in range(3):  # a fixed count keeps the ranks' collectives matched
                 step()
         else:
             t_end = time.perf_counter() + args.prewarm_ms / 1e3
@@ -179,32 +262,45 @@ def main():
                 torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
     if dist:
         dist.barrier()
-    torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    sync()
+    if args.stub:
+        evs = []
+    else:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for a, b in evs:
-        a.record()
-        step()
-        b.record()
-    torch.cuda.synchronize()
+    if evs:
+        for a, b in evs:
+            a.record()
+            step()
+            b.record()
+    else:
+        for _ in range(args.steps):
+            step()
+    sync()
     if dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))  # HIP events on the launch stream
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs])) if evs else dt / max(1, args.steps) * 1e3
     if dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if args.mode != "shard" and dist and rank == 0 and args.stub:
+        routing_ok = bool(torch.equal(d_all_out, d_all[:, :out_len]))  # every frame came back to its own row
 
     result = None
     if rank == 0:
         total_bits = float(world) * n * FRAMEBITS * args.steps
-        alg_bytes = n * (4 * (FRAMEBITS + TAIL) + FRAMEBITS // 8)  # 3192 B per FIC frame
+        alg_bytes = n * (4 * (FRAMEBITS + TAIL) + out_len)  # 3192 B per FIC frame
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        sharding_note = {"shard": "independent shards per rank, no data-path collective",
+                         "scatter": "rank 0 owns all frames: chunked, overlapped RCCL send/recv pipeline "
+                                    "(%d frames per rank per chunk) inside the step" % args.chunk_frames,
+                         "scatter-plain": "rank 0 owns all frames: one round-robin scatter + one gather inside the step"}
         result = {
             "metric": "decoded Mbit/s per GPU on batched 768-bit DAB FIC frames; bit-exact vs AVX2 ref",
             "value": round(total_bits / dt / 1e6, 1),
@@ -218,25 +314,27 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "batch=65536 FIC frames (768 bit, 3096 soft symbols u8) per GPU, "
-                                   "resident in HBM; Eb/N0=3 dB reference-style noise",
+            "config": {"workload": "batch=%d FIC frames (768 bit, 3096 soft symbols u8) per GPU, "
+                                   "resident in HBM; Eb/N0=3 dB reference-style noise" % n,
                        "frames_per_gpu": n, "framebits": FRAMEBITS, "kernel": args.kernel, "prewarm_ms": args.prewarm_ms,
-                       "sharding": ("independent shards per rank, no data-path collective" if args.mode == "shard"
-                                    else "rank 0 owns all frames: round-robin RCCL scatter + gather inside the step")},
+                       "sharding": sharding_note[args.mode],
+                       "launch": "spawned by bench.py" if os.environ.get("VIT_BENCH_SPAWNED") else
+                                 ("external launcher" if spawned else "single process")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": alg_bytes},
         }
-        traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(traffic_file):
-            try:
-                with open(traffic_file) as f:
-                    result["roofline"]["traffic"] = json.load(f).get("hbm_bytes_per_launch")
-            except (OSError, ValueError):
-                pass
-        if args.mode == "scatter":
+        if args.stub:
+            result["stub"] = True
+            result["data"] = "stub (CPU rehearsal of the launcher; value is NOT a measurement)"
+            result["roofline"] = None
+            if routing_ok is not None:
+                result["routing_ok"] = routing_ok
+        else:
+            _attach_cached_counters(result)
+        if args.mode != "shard" and result.get("roofline"):
             result["roofline"]["note"] = "kernel_ms here spans scatter+decode+gather; see shard mode for the kernel"
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not args.no_cpu and not args.stub:
             O = _vitpkg.load_oracle()  # checker + timed CPU baseline only
             sym_host = d_sym.cpu().numpy()
             base, ref = cpu_baseline(O, sym_host, FRAMEBITS)
@@ -252,6 +350,25 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return result
+
+
+def _attach_cached_counters(result):
+    """PMC-derived figures cannot be collected inside a timed run: they come from the committed rocprofv3 passes
+    of this same command (tools/collect_profiles.sh -> profiles/pmc_traffic.json) and are labelled as such."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            pmc = json.load(f)
+    except (OSError, ValueError):
+        return
+    r = result["roofline"]
+    r["traffic"] = pmc.get("hbm_bytes_per_launch")
+    r["traffic_source"] = "cached from profiles/pmc_traffic.json (%s)" % pmc.get("source", "rocprofv3 --pmc passes")
+    for k in ("valu_busy", "valu_insts_per_frame_step", "valu_insts_per_wave"):
+        if k in pmc:
+            r[k] = pmc[k]
+    if "valu_busy" in pmc:
+        r["binding_resource"] = "VALU issue (see valu_busy); the HBM frac is reported as the north star asks"
 
 
 if __name__ == "__main__":

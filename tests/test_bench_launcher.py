@@ -1,0 +1,48 @@
+"""bench.py's own launcher: `python bench.py --gpus N` without WORLD_SIZE must start N ranks and print ONE JSON line
+with n_gpus = N.  Rehearsed here on CPU: backend gloo, decoder replaced by bench.py's byte-copy stand-in (--stub),
+so what runs is the real spawn path, rendezvous, barriers, max-over-ranks timing and - in the scatter modes - the
+real collectives with a routing check."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "gloo", "--stub", "--steps", "2",
+                        "--warmup", "1", "--frames", "48"] + extra, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout  # exactly one JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("mode,extra", [("shard", []), ("scatter", ["--chunk-frames", "10"]),
+                                        ("scatter", ["--chunk-frames", "8", "--root-frames", "20"]),
+                                        ("scatter-plain", [])])
+def test_bare_command_spawns_two_ranks(mode, extra):
+    r = _run(["--gpus", "2", "--mode", mode] + extra)
+    assert r["n_gpus"] == 2 and r["stub"] is True and r["steps"] == 2
+    assert r["config"]["launch"] == "spawned by bench.py"
+    assert r["scaling"] == "weak" and r["unit"] == "Mbit/s"
+    if mode != "shard":
+        assert r["routing_ok"] is True
+
+
+def test_three_ranks_and_forced_spawn_of_one():
+    assert _run(["--gpus", "3", "--mode", "scatter", "--chunk-frames", "7"])["n_gpus"] == 3
+    r = _run(["--gpus", "1", "--spawn"])
+    assert r["n_gpus"] == 1 and r["config"]["launch"] == "spawned by bench.py"
+
+
+def test_under_an_external_launcher_it_is_a_rank():
+    """WORLD_SIZE in the environment (torch.distributed.run): no second level of children"""
+    r = _run(["--gpus", "1"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                               "MASTER_PORT": "29731"})
+    assert r["n_gpus"] == 1 and r["config"]["launch"] == "external launcher"

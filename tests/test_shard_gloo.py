@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, nframes, framebits, q):
+def _worker(rank, world, port, nframes, framebits, q, pipeline=None):
     sys.path.insert(0, ROOT)
     import _vitpkg
     import torch.distributed as dist
@@ -42,10 +42,21 @@ def _worker(rank, world, port, nframes, framebits, q):
 
         def decode(local):  # oracle stands in for the HIP path on CPU
             if local.shape[0] == 0:
-                return torch.empty((0, framebits // 8), dtype=torch.uint8)
+                return torch.empty((0, (framebits + 7) // 8), dtype=torch.uint8)
             return torch.from_numpy(O.decode_batch(framebits, local.numpy()))
 
-        full = sharding.decode_sharded(sym_all, nframes, framebits, decode)
+        def decode_into(local, out):
+            out.copy_(decode(local))
+
+        olen = (framebits + 7) // 8
+        if pipeline is None:
+            full = sharding.decode_sharded(sym_all, nframes, framebits, decode)
+        else:
+            chunk, rootf = pipeline
+            full = torch.full((nframes, olen), 0xEE, dtype=torch.uint8) if rank == 0 else None
+            for _ in range(2):  # twice: buffers and message order must survive a second pass
+                plan = sharding.decode_stream(sym_all, full, nframes, framebits, decode_into, chunk, rootf)
+            assert sum(plan.block(k, r)[1] for k in range(plan.nchunks) for r in range(world)) == nframes
         if rank == 0:
             want = O.decode_batch(framebits, sym_all.numpy())
             q.put(("ok", bool(np.array_equal(full.numpy(), want)),
@@ -72,6 +83,54 @@ def test_round_robin_scatter_decode_gather(nframes):
     assert equal
     assert sum(counts) == nframes and counts[0] - counts[1] in (0, 1)
     assert all(p.exitcode == 0 for p in procs)
+
+
+def _run(world, nframes, framebits, pipeline):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nframes, framebits, q, pipeline)) for r in range(world)]
+    [p.start() for p in procs]
+    status, equal, counts = q.get(timeout=180)
+    [p.join(60) for p in procs]
+    assert status == "ok", equal
+    assert equal
+    assert all(p.exitcode == 0 for p in procs)
+
+
+def test_round_robin_partial_last_byte():
+    """framebits % 8 != 0: (framebits+7)//8 output bytes per frame through scatter and gather"""
+    _run(2, 9, 770, None)
+
+
+@pytest.mark.parametrize("nframes,chunk,rootf", [(37, 4, None), (64, 8, 24), (5, 16, None), (33, 3, 1)])
+def test_chunked_pipeline_scatter_decode_gather(nframes, chunk, rootf):
+    """decode_stream: contiguous blocks, double-buffered receives, outputs sent back while the next chunk decodes"""
+    _run(2, nframes, 288, (chunk, rootf))
+
+
+def test_chunked_pipeline_three_ranks_partial_byte():
+    _run(3, 29, 10, (2, 3))
+
+
+def test_stream_plan_math():
+    sys.path.insert(0, ROOT)
+    import _vitpkg
+    _vitpkg.load_package()
+    from importlib import import_module
+    sh = import_module("viterbi_dll_amd.sharding")
+    for n in (0, 1, 7, 64, 1000):
+        for w in (1, 2, 3, 8):
+            for chunk, rootf, root in ((1, None, 0), (4, None, 0), (16, 40, 0), (5, 2, w - 1)):
+                plan = sh.StreamPlan(n, w, chunk, rootf, root)
+                seen = []
+                for k in range(plan.nchunks):
+                    for r in range(w):
+                        lo, c = plan.block(k, r)
+                        assert 0 <= c <= plan.max_block(r)
+                        seen += list(range(lo, lo + c))
+                        assert all(plan.owner(f) == r for f in range(lo, lo + c))
+                assert sorted(seen) == list(range(n))  # every frame exactly once
 
 
 def test_shard_index_math():

@@ -19,19 +19,20 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, extra=()):
-    if not force and not _stale():
+def build(force=False, verbose=False, extra=(), out=None):
+    """extra/out: kernel experiments (tools/exp/ab.sh) build flag variants next to the product library"""
+    if out is None and not force and not _stale():
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC,
            "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"),
-           "-o", SO] + list(extra) + [os.path.join(CSRC, s) for s in SOURCES]
+           "-o", out or SO] + list(extra) + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return SO
+    return out or SO
 
 
 if __name__ == "__main__":

@@ -471,16 +471,22 @@ u32 traceback_part(const char* dec, u32* scratch, u32* img, u32 fstride, u32 lan
 }
 
 // Single-segment kernel: every frame of the launch fits 49 blocks (framebits <= 778; the FIC fast path).
+#ifndef VIT_STAGGER
+#define VIT_STAGGER 0  /* persistent variants only: start-up delay per wave slot, in cycles per trellis step */
+#endif
+#ifndef VIT_PERSIST
+#define VIT_PERSIST 0  /* 0: one workgroup per group of 4 frames (default: measured fastest, profiles/r02_ab_persist.txt);
+                          1: persistent, static stride; 2: persistent, atomic counter */
+#endif
 template <bool SYM32>
 __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict__ sym, uint8_t* __restrict__ out,
                                                         const vit_frame_desc* __restrict__ desc, u32 framebits_uniform,
-                                                        long long nframes, PkLayout lay) {
+                                                        long long nframes, PkLayout lay, u32 ngroups, unsigned* counter) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* dec = lds;                  // [block - R][lane] -> (acc0, acc1); the last block spills into tab
     char* tab = lds + lay.dec_bytes;  // [tau][pair][c] -> M; after the ACS: last block, scratch, image
     u32* img = reinterpret_cast<u32*>(lds + lay.img_off);  // output bit image, 4 frames
     const u32 lane = threadIdx.x;
-    const long long f0 = (long long)blockIdx.x * 4;
 #if VIT_PRIO
     // Stagger the waves that share a SIMD: different issue priorities make them drift apart, so the
     // latency-bound traceback of one overlaps the ACS of the others instead of all four hitting it together.
@@ -496,6 +502,52 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
     }
 #endif
 
+    // ---- lane constants ----
+    const u32 l5 = lane & 31u, pair = lane >> 5;
+    Lanes L;
+#pragma unroll
+    for (int rho = 0; rho < 5; rho++) {
+        const u32 i = ((l5 << rho) | (l5 >> (5 - rho))) & 31u;  // butterfly index rol5(l, rho)
+        const u32 i0 = i & 1u, i1 = (i >> 1) & 1u, i2 = (i >> 2) & 1u, i3 = (i >> 3) & 1u, i4 = (i >> 4) & 1u;
+        const u32 c = (i1 ^ i2 ^ i4) | ((i0 ^ i1 ^ i2) << 1) | ((i0 ^ i3) << 2);  // parity((2i)&poly_j), const.asm:27-63
+        L.toff[rho] = pair * 32u + c * 4u;
+    }
+    Consts C;
+    C.hi = HI;
+    asm volatile("" : "+v"(C.hi));  // keep it in a VGPR
+    const u32 tau = lane >> 1, pp = lane & 1u;  // pre-pass lane = (tau, pair pp)
+    u32 sel[4];
+    {
+        const u32 hb = (tau & 1u) ? 0x0C000C00u : 0x0D000D00u;  // even step: 0xFF high bytes (= +0xFF00)
+#pragma unroll
+        for (int k = 0; k < 4; k++) sel[k] = hb | (0x00040000u + 0x00010001u * k);  // byte k of half 0 / half 1
+    }
+
+    // Workgroups are persistent: as many as fit the chip, each takes group after group of 4 frames
+    // (static stride, or the next one from an atomic counter), so the per-workgroup set-up and the LDS
+    // allocation are paid once and the waves of a SIMD drift apart instead of marching in rounds.
+#if VIT_PERSIST && VIT_STAGGER
+    // Persistent waves that start together stay phase-locked: all four waves of a SIMD reach their (latency-bound)
+    // tracebacks at the same time, round after round.  Delay wave slot s by s quarters of a group's run time
+    // ONCE; while a slot sleeps the others have the SIMD to themselves, so little is lost.
+    {
+        u32 hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        const u32 naps = ((hwid & 3u) * (lay.maxfb + VIT_TAIL) * (u32)VIT_STAGGER) >> 13;  // 8128 cycles per nap
+        for (u32 i = 0; i < naps; i++) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
+#if VIT_PERSIST == 2
+    for (;;) {
+        u32 grp = 0;
+        if (lane == 0) grp = atomicAdd(counter, 1u);
+        grp = (u32)__builtin_amdgcn_readfirstlane((int)grp);
+        if (grp >= ngroups) break;
+#else
+    (void)counter;
+    for (u32 grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+#endif
+    const long long f0 = (long long)grp * 4;
     // ---- per-frame parameters (wave-uniform loads) ----
     u32 fbits[4];
     size_t soff[4], ooff[4];
@@ -521,37 +573,17 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
         }
         maxfb = fbits[k] > maxfb ? fbits[k] : maxfb;
     }
-    if (maxfb == 0) return;
+    if (maxfb == 0) continue;
     const u32 nb = (maxfb + VIT_TAIL + 15u) >> 4, R = pk_reg_blocks(nb);
     const u32 fstride = pk_img_stride(maxfb);  // image dwords per frame (+ slack for the shifted spill)
     const u32 T_max = maxfb + VIT_TAIL;
 
-    // ---- ACS lane constants ----
-    const u32 l5 = lane & 31u, pair = lane >> 5;
-    Lanes L;
-#pragma unroll
-    for (int rho = 0; rho < 5; rho++) {
-        const u32 i = ((l5 << rho) | (l5 >> (5 - rho))) & 31u;  // butterfly index rol5(l, rho)
-        const u32 i0 = i & 1u, i1 = (i >> 1) & 1u, i2 = (i >> 2) & 1u, i3 = (i >> 3) & 1u, i4 = (i >> 4) & 1u;
-        const u32 c = (i1 ^ i2 ^ i4) | ((i0 ^ i1 ^ i2) << 1) | ((i0 ^ i3) << 2);  // parity((2i)&poly_j), const.asm:27-63
-        L.toff[rho] = pair * 32u + c * 4u;
-    }
-    Consts C;
-    C.hi = HI;
-    asm volatile("" : "+v"(C.hi));  // keep it in a VGPR
-    // ---- pre-pass lane constants: lane = (tau = lane>>1, pair pp = lane&1) ----
-    const u32 tau = lane >> 1, pp = lane & 1u;
+    // ---- pre-pass frame pointers: lane = (tau = lane>>1, pair pp = lane&1) ----
     const u32 a_fb = pp ? fbits[2] : fbits[0], b_fb = pp ? fbits[3] : fbits[1];
     const u32 a_T = a_fb ? a_fb + VIT_TAIL : 0u, b_T = b_fb ? b_fb + VIT_TAIL : 0u;
     constexpr size_t SB = SYM32 ? 4 : 1;  // bytes per soft symbol in memory
     const uint8_t* a_sym = sym + SB * (pp ? soff[2] : soff[0]);
     const uint8_t* b_sym = sym + SB * (pp ? soff[3] : soff[1]);
-    u32 sel[4];
-    {
-        const u32 hb = (tau & 1u) ? 0x0C000C00u : 0x0D000D00u;  // even step: 0xFF high bytes (= +0xFF00)
-#pragma unroll
-        for (int k = 0; k < 4; k++) sel[k] = hb | (0x00040000u + 0x00010001u * k);  // byte k of half 0 / half 1
-    }
     u32 A = l5 == 0 ? 0u : 0x003F003Fu, B = 0x003F003Fu;  // const.asm:19-25 (0-based, step 0 is even)
     u32 acc0 = 0, acc1 = 0;
     v32u r0, r1;  // register-resident decisions of blocks [0,R)
@@ -628,6 +660,8 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
             }
         }
     }
+    __syncthreads();  // the image is read before the next group's pre-pass reuses the region
+    }  // persistent loop
 }
 
 // ---- frames longer than one segment: decisions beyond the last 17 blocks go through HBM ---------
@@ -854,24 +888,45 @@ bool sort_enabled() {
     return on;
 }
 
+// CUs of a device (persistent grids are sized by it), cached per device
+static int device_cus(int dev) {
+    static std::mutex mu;
+    static int cus[64] = {0};
+    if (dev < 0 || dev >= 64) return 256;
+    std::lock_guard<std::mutex> lk(mu);
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
 hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, const vit_frame_desc* d_desc,
                          uint32_t framebits, uint32_t max_framebits, int64_t nframes, hipStream_t stream) {
     const uint8_t* d_sym = static_cast<const uint8_t*>(d_symbols);
     if (sym32 && (reinterpret_cast<uintptr_t>(d_symbols) & 15u)) return hipErrorInvalidValue;  // uint4 loads
     if (nframes <= 0) return hipSuccess;
     if (!vit_pk_supported(max_framebits)) return hipErrorInvalidValue;
-    static std::once_flag attr_once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(attr_once, [] {
-        const void* ks[4] = {reinterpret_cast<const void*>(vit_pk_kernel<false>),
-                             reinterpret_cast<const void*>(vit_pk_kernel<true>),
-                             reinterpret_cast<const void*>(vit_pk_long_kernel<false>),
-                             reinterpret_cast<const void*>(vit_pk_long_kernel<true>)};
-        for (const void* k : ks)
-            if (attr_err == hipSuccess)
-                attr_err = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
-    if (attr_err != hipSuccess) return attr_err;
+    hipError_t e;
+    int dev = 0;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+    // the dynamic-LDS opt-in is per device: once per (device, kernel)
+    {
+        static std::mutex mu;
+        static uint64_t done = 0;
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev >= 0 && dev < 64 && !((done >> dev) & 1u)) {
+            const void* ks[4] = {reinterpret_cast<const void*>(vit_pk_kernel<false>),
+                                 reinterpret_cast<const void*>(vit_pk_kernel<true>),
+                                 reinterpret_cast<const void*>(vit_pk_long_kernel<false>),
+                                 reinterpret_cast<const void*>(vit_pk_long_kernel<true>)};
+            for (const void* k : ks)
+                if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess)
+                    return e;
+            done |= 1ull << dev;
+        }
+    }
     const long long groups = (nframes + 3) / 4;
     if (groups > 0x7FFFFFFFLL) return hipErrorInvalidValue;
     const u32 nblk = (max_framebits + VIT_TAIL + 15u) >> 4;
@@ -881,31 +936,29 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
     const bool is_long = nblk > SEG_BLOCKS;
 #endif
     const bool sort = d_desc != nullptr && nframes >= SORT_MIN_FRAMES && sort_enabled();
-    if (!is_long && !sort) {
-        const PkLayout lay = pk_layout(max_framebits);
-        if (sym32)
-            hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)groups), dim3(64), lay.total, stream, d_sym, d_out,
-                               d_desc, framebits, (long long)nframes, lay);
-        else
-            hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)groups), dim3(64), lay.total, stream, d_sym, d_out,
-                               d_desc, framebits, (long long)nframes, lay);
-        return hipGetLastError();
-    }
     const PkLayout lay = is_long ? pk_layout_long(max_framebits) : pk_layout(max_framebits);
-    hipError_t e;
+    // persistent workgroups: as many as fit the chip
     long long grid = groups;
-    u32 spill_blocks = 0;
-    int dev = 0;
-    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
-    if (is_long) {  // persistent workgroups: as many as fit the chip
-        int cus = 0;
-        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+#if VIT_PERSIST == 0
+    if (is_long)
+#endif
+    {
         u32 per_cu = (160u * 1024u) / lay.total;
         if (per_cu > 16u) per_cu = 16u;  // 4 waves per SIMD (launch bounds)
-        grid = (long long)per_cu * cus;
+        grid = (long long)per_cu * device_cus(dev);
         if (grid > groups) grid = groups;
-        spill_blocks = nblk - LONG_LDS_BLOCKS;
     }
+    const bool need_counter = is_long || VIT_PERSIST == 2;
+    if (!need_counter && !sort) {
+        if (sym32)
+            hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
+                               d_desc, framebits, (long long)nframes, lay, (u32)groups, (unsigned*)nullptr);
+        else
+            hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
+                               d_desc, framebits, (long long)nframes, lay, (u32)groups, (unsigned*)nullptr);
+        return hipGetLastError();
+    }
+    const u32 spill_blocks = is_long ? nblk - LONG_LDS_BLOCKS : 0u;
     const size_t desc_bytes = sort ? (((size_t)nframes * sizeof(vit_frame_desc) + 255u) & ~(size_t)255u) : 0u;
     const size_t need = SCRATCH_HDR + desc_bytes + (size_t)grid * spill_blocks * DEC_BLOCK;
     ScratchCtx& sc = t_scratch;
@@ -930,10 +983,10 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
             return e;
         d_desc = sorted;
     }
+    unsigned* counter = reinterpret_cast<unsigned*>(base);
+    if (need_counter && (e = hipMemsetAsync(base, 0, 256, stream)) != hipSuccess) return e;
     if (is_long) {
-        if ((e = hipMemsetAsync(base, 0, 256, stream)) != hipSuccess) return e;
         uint2* spill = reinterpret_cast<uint2*>(base + SCRATCH_HDR + desc_bytes);
-        unsigned* counter = reinterpret_cast<unsigned*>(base);
         if (sym32)
             hipLaunchKernelGGL(vit_pk_long_kernel<true>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
                                d_desc, framebits, (long long)nframes, lay, spill, spill_blocks, counter, (u32)groups);
@@ -941,11 +994,11 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
             hipLaunchKernelGGL(vit_pk_long_kernel<false>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
                                d_desc, framebits, (long long)nframes, lay, spill, spill_blocks, counter, (u32)groups);
     } else if (sym32) {
-        hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)groups), dim3(64), lay.total, stream, d_sym, d_out,
-                           d_desc, framebits, (long long)nframes, lay);
+        hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
+                           d_desc, framebits, (long long)nframes, lay, (u32)groups, counter);
     } else {
-        hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)groups), dim3(64), lay.total, stream, d_sym, d_out,
-                           d_desc, framebits, (long long)nframes, lay);
+        hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
+                           d_desc, framebits, (long long)nframes, lay, (u32)groups, counter);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     return hipEventRecord(sc.ev, stream);

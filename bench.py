@@ -126,10 +126,13 @@ def parse_args(argv=None):
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
                     help="untimed GPU pre-conditioning before the W warm-up steps: the MI355X needs ~15 ms of sustained load "
                          "to reach its steady-state clocks (first launches run ~10 %% slower, tools/exp/trend.py)")
-    ap.add_argument("--mode", choices=["shard", "scatter", "scatter-plain"], default="shard",
+    ap.add_argument("--mode", choices=["shard", "scatter", "scatter-plain", "multi"], default="shard",
                     help="shard: every rank owns its frames (default, no collective); scatter: rank 0 owns all frames, "
                          "chunked + overlapped RCCL send/recv pipeline inside the timed step (config 4, "
-                         "sharding.decode_stream); scatter-plain: ONE scatter + decode + ONE gather (f mod N)")
+                         "sharding.decode_stream); scatter-plain: ONE scatter + decode + ONE gather (f mod N); multi: ONE "
+                         "process drives all --gpus devices through the C ABI (vit_decode_stream_multi, same pipeline)")
+    ap.add_argument("--loopback", action="store_true",
+                    help="multi mode: add the RCCL loop-back rank on the root device (self-test on a one-GPU box)")
     ap.add_argument("--chunk-frames", type=int, default=32768, help="scatter mode: frames per rank per chunk")
     ap.add_argument("--root-frames", type=int, default=None,
                     help="scatter mode: frames the root keeps per chunk (default = --chunk-frames)")
@@ -179,6 +182,8 @@ def stub_decode(sym_block, out_block):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else list(argv)
     args = parse_args(argv)
+    if args.mode == "multi":
+        return main_multi(args)
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
         rc = spawn_ranks(args, argv)
         if rc:
@@ -349,6 +354,50 @@ def main(argv=None):
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    return result
+
+
+def main_multi(args):
+    """ONE process, --gpus devices, the C-ABI pipeline: the whole stream (frames x gpus) lives on GPU 0."""
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    V = _vitpkg.load_package()
+    assert V.device_count() >= args.gpus, "libviterbi.so sees %d gfx950 device(s)" % V.device_count()
+    V.initialize()
+    V.set_kernel(args.kernel)
+    n_total = args.frames * args.gpus
+    out_len = (FRAMEBITS + 7) // 8
+    d_all = make_frames(n_total, FRAMEBITS, seed=99, device=dev)
+    d_all_out = torch.zeros((n_total, out_len), dtype=torch.uint8, device=dev)
+    devices = list(range(args.gpus))
+    flags = V.MULTI_LOOPBACK if args.loopback else 0
+    rootf = -1 if args.root_frames is None else args.root_frames
+
+    def step():
+        V.decode_stream_multi(d_all, d_all_out, FRAMEBITS, n_total, devices, args.chunk_frames, rootf, flags)
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()  # synchronous
+    dt = time.perf_counter() - t0
+    ref = torch.zeros_like(d_all_out)
+    V.decode_batch_dev(d_all, ref, FRAMEBITS, n_total)
+    torch.cuda.synchronize()
+    same = bool(torch.equal(ref, d_all_out))
+    result = {
+        "metric": "decoded Mbit/s per GPU on batched 768-bit DAB FIC frames; bit-exact vs AVX2 ref",
+        "value": round(n_total * FRAMEBITS * args.steps / dt / 1e6, 1) if same else 0.0, "unit": "Mbit/s",
+        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong-per-stream", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "stream of %d FIC frames resident on GPU 0, decoded by %d GPU(s) through "
+                               "vit_decode_stream_multi (RCCL send/recv pipeline)" % (n_total, args.gpus),
+                   "chunk_frames": args.chunk_frames, "root_frames": rootf, "loopback": bool(args.loopback),
+                   "launch": "single process, C ABI"},
+        "roofline": None, "multi_matches_single_launch": same,
+    }
+    print(json.dumps(result), flush=True)
     return result
 
 

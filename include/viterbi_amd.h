@@ -85,7 +85,9 @@ int vit_device_count(void);
 
 /* Frame descriptor for variable-length batches.
  * sym_offset: byte offset of the frame's first soft symbol in the u8 symbol
- * buffer, multiple of 4; the frame owns 4*(framebits+6) bytes from there.
+ * buffer; MUST be a multiple of 4 (the kernels load one dword per trellis step) -
+ * a descriptor that is not is skipped like one with an invalid length, its
+ * output stays untouched; the frame owns 4*(framebits+6) bytes from there.
  * out_offset: byte offset of its (framebits+7)/8 output bytes. */
 typedef struct vit_frame_desc {
     uint64_t sym_offset;
@@ -160,6 +162,34 @@ int vit_set_batch_window_us(int microseconds);
  * reference kernel, 2 = packed 4-frames-per-wave kernel.  Returns the old
  * value.  Affects later vit_decode_* calls of the whole process. */
 int vit_set_kernel(int which);
+
+/* ------------------------------------------------------------------------ *
+ * Part 3 -- several GPUs behind one call (BASELINE.json configs[3], SURVEY 8e;
+ * not in the reference, whose only concurrency is caller threads, README.md:56)
+ * ------------------------------------------------------------------------ */
+
+/* ONE host process, ndev gfx950 devices (HIP ordinals in devices[], distinct; devices[0] is the "root").
+ * nframes equal-length frames in the device format live on the root (d_symbols_u8), the decoded bytes
+ * are wanted there too (d_decoded).  The stream is cut into chunks of
+ *     root_frames + (ndev-1) * chunk_frames
+ * consecutive frames; of every chunk the root decodes the first root_frames itself and devices[i]
+ * (i >= 1) the i-th block of chunk_frames frames: round-robin at block granularity, so each block is
+ * a contiguous slice that RCCL sends from / receives into place (ncclSend/ncclRecv over xGMI, one
+ * ncclGroupStart/End per pipeline step, librccl dlopen'ed on first use).  Block k+1 travels while
+ * block k is being decoded and the decoded bytes of block k-1 come back (double buffers per device).
+ *   root_frames : -1 = chunk_frames; 0 = the root only distributes (ndev > 1); larger values give the
+ *                 root a bigger share (its peers are fed through one xGMI link each)
+ *   stream      : the root-device stream that produced d_symbols_u8 (NULL = default stream); the
+ *                 transfers start behind it
+ *   flags       : VIT_MULTI_LOOPBACK adds one more rank ON THE ROOT DEVICE that is fed through RCCL
+ *                 like a remote peer (self send/recv) - a self-test of the pipeline on a one-GPU box
+ * SYNCHRONOUS: returns when every byte of d_decoded is in place.  One call at a time per process
+ * (internal mutex); streams, communicators and buffers are cached between calls with the same devices.
+ * The caller's current device is restored.  ndev == 1 without the flag needs no RCCL. */
+#define VIT_MULTI_LOOPBACK 0x1u
+int vit_decode_stream_multi(const uint8_t *d_symbols_u8, uint8_t *d_decoded, uint32_t framebits,
+                            int64_t nframes, const int *devices, int ndev, int64_t chunk_frames,
+                            int64_t root_frames, unsigned flags, void *stream);
 
 #ifdef __cplusplus
 }

@@ -3,8 +3,10 @@
 PROVENANCE: produced by THIS repo's oracle (oracle/vit_oracle.c), not by the reference --
 the reference cannot be built or run under this project's rules (it needs stand-ins for
 <windows.h>/<psapi.h> and MASM data).  The oracle itself is pinned by SURVEY 8c's KATs
-(tests/test_oracle_kat.py).  Inputs are regenerated from seeds; expected outputs are stored.
+(tests/test_oracle_kat.py).  Inputs AND expected outputs are stored (inputs as base64, plus their seed and FNV-1a-64), so that the GPU
+suite can compare the HIP path with the committed bytes without loading the oracle at all.
 """
+import base64
 import json
 import os
 import sys
@@ -23,6 +25,7 @@ for fb, kind, seed in [(768, "uniform", 88172645463325252), (288, "uniform", 881
     sym = O.uniform_symbols(O.sym_len(fb), seed=seed) if kind == "uniform" else O.noisy_frames(1, fb, seed=seed)[0]
     out = O.decode_batch(fb, sym)[0]
     g["decode"].append({"framebits": fb, "kind": kind, "seed": seed, "sym_fnv1a64": "%016x" % O.fnv1a64(sym),
+                        "sym_b64": base64.b64encode(sym.tobytes()).decode(),
                         "out_hex": out.tobytes().hex()})
 rng = np.random.default_rng(2024)
 for rsdims, errs in [(4, [0, 2, 5, 1]), (4, [1, 6, 0, 0]), (6, [5, 5, 5, 5, 5, 5]), (3, [0, 0, 7])]:

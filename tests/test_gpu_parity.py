@@ -224,31 +224,40 @@ def test_random_lengths_and_batch_sizes(V, O, torch_cuda):
         assert np.array_equal(got, want), "framebits=%d n=%d" % (fb, n)
 
 
-def test_varlen_device_sort_mixed_and_invalid(V, O, torch_cuda):
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+def test_varlen_device_sort_mixed_and_invalid(V, O, torch_cuda, kernel):
     """the launcher length-sorts a copy of the table on the device (csrc/vit_sort.hip): a few thousand mixed
     lengths incl. long (spilled) frames, many equal keys, and descriptors the launch was not sized for --
-    every valid frame bit-exact, invalid ones untouched, the caller's table unmodified"""
+    every valid frame bit-exact, invalid ones (too long, odd length, symbols not dword aligned) untouched,
+    the caller's table unmodified; for the automatic choice and for both kernels"""
     torch = torch_cuda
     rng = np.random.default_rng(77)
     fbs = (8 * rng.integers(1, 40, 2500)).tolist() + [768] * 700 + (96 * rng.integers(3, 73, 60)).tolist() + [9216, 8]
     rng.shuffle(fbs)
     fbs = [int(x) for x in fbs]
     desc, sym_bytes, out_bytes = V.make_descs(fbs)
-    bad_long, bad_odd = 5, 1234
+    bad_long, bad_odd, bad_align = 5, 1234, 2001
     sym = O.uniform_symbols(sym_bytes, seed=11)
     want = np.full(out_bytes, 0x5A, np.uint8)
     for i, (fb, d) in enumerate(zip(fbs, desc)):
         so, oo = int(d["sym_offset"]), int(d["out_offset"])
-        if i not in (bad_long, bad_odd):
+        if i not in (bad_long, bad_odd, bad_align):
             want[oo:oo + fb // 8] = O.decode_batch(fb, sym[so:so + O.sym_len(fb)])[0]
     desc["framebits"][bad_long] = 9216 + 8   # beyond max_framebits
     desc["framebits"][bad_odd] = fbs[bad_odd] + 1  # odd: not a valid frame length
+    desc["sym_offset"][bad_align] += 2  # the kernels load one dword per trellis step
     d_desc = torch.from_numpy(desc.view(np.uint8)).cuda()
     d_out = torch.full((out_bytes,), 0x5A, dtype=torch.uint8, device="cuda")
-    V.decode_varlen_dev(torch.from_numpy(sym).cuda(), d_out, d_desc, len(fbs), 9216)
-    torch.cuda.synchronize()
+    old = V.set_kernel(kernel)
+    try:
+        V.decode_varlen_dev(torch.from_numpy(sym).cuda(), d_out, d_desc, len(fbs), 9216)
+        torch.cuda.synchronize()
+    finally:
+        V.set_kernel(old)
     assert np.array_equal(d_out.cpu().numpy(), want)
     assert np.array_equal(d_desc.cpu().numpy(), desc.view(np.uint8))
+    if kernel:
+        return
     # and a short-frame-only table (single-segment kernel behind the sort)
     fbs2 = [int(x) for x in 8 * rng.integers(1, 97, 500)]
     desc2, sb2, ob2 = V.make_descs(fbs2)

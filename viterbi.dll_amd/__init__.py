@@ -23,7 +23,9 @@ EXPORTS = [
     "vit_last_error", "vit_device_count", "vit_set_kernel", "vit_set_batch_window_us", "vit_decode_batch_dev",
     "vit_decode_batch_dev_u32", "vit_decode_varlen_dev", "vit_pack_symbols_dev", "vit_sort_descs",
     "vit_decode_batch_host", "vit_rs_batch_dev", "vit_rs_batch_host", "vit_dabplus_superframes_dev",
+    "vit_decode_stream_multi",
 ]
+MULTI_LOOPBACK = 0x1
 
 
 class ViterbiError(RuntimeError):
@@ -78,6 +80,7 @@ def lib():
         L.vit_rs_batch_dev.argtypes = [vp, vp, vp, C.c_uint32, C.c_int64, vp]
         L.vit_rs_batch_host.argtypes = [vp, vp, vp, C.c_uint32, C.c_int64]
         L.vit_dabplus_superframes_dev.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_int64, vp]
+        L.vit_decode_stream_multi.argtypes = [vp, vp, C.c_uint32, C.c_int64, vp, C.c_int, C.c_int64, C.c_int64, C.c_uint, vp]
         _lib = L
     return _lib
 
@@ -213,6 +216,15 @@ def dabplus_superframes_dev(d_symbols_u8, d_work, d_rs_out, d_ret, RSDims, nsf, 
     _check(lib().vit_dabplus_superframes_dev(C.c_void_p(d_symbols_u8.data_ptr()), C.c_void_p(d_work.data_ptr()),
                                              C.c_void_p(d_rs_out.data_ptr()), C.c_void_p(d_ret.data_ptr()),
                                              RSDims, nsf, _stream_ptr(stream)), "vit_dabplus_superframes_dev")
+
+
+def decode_stream_multi(d_symbols_u8, d_out, framebits, nframes, devices, chunk_frames, root_frames=-1, flags=0,
+                        stream=None):
+    """ONE process, several GPUs (include/viterbi_amd.h Part 3): the stream lives on devices[0]; synchronous."""
+    devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+    _check(lib().vit_decode_stream_multi(C.c_void_p(d_symbols_u8.data_ptr()), C.c_void_p(d_out.data_ptr()), framebits,
+                                         nframes, devs, len(devices), chunk_frames, root_frames, flags,
+                                         _stream_ptr(stream)), "vit_decode_stream_multi")
 
 
 def make_descs(framebits_list, sym_align=4):

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libviterbi.so")
-SOURCES = ["vit_api.hip", "vit_wave.hip", "vit_pk.hip", "vit_sort.hip", "rs_kernels.hip"]
+SOURCES = ["vit_api.hip", "vit_wave.hip", "vit_pk.hip", "vit_sort.hip", "rs_kernels.hip", "vit_multi.hip"]
 DEPS = SOURCES + ["vit_internal.h", "exports.map"]
 
 
@@ -28,7 +28,7 @@ def build(force=False, verbose=False, extra=(), out=None):
            "-Wall", "-Wno-unused-function",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC,
            "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"),
-           "-o", out or SO] + list(extra) + [os.path.join(CSRC, s) for s in SOURCES]
+           "-o", out or SO] + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -482,9 +482,8 @@ hipError_t rs_launch(const uint8_t* d_p, uint8_t* d_out, int32_t* d_ret, uint32_
     if (groups > (1 << 20)) groups = 1 << 20;
     if (rsdims <= RS_THREADS) {
         // persistent workgroups (4 fit a CU): each walks its groups with the next input block already in flight
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            cus = 256;
+        int dev = 0;
+        const int cus = hipGetDevice(&dev) == hipSuccess ? vit_device_cus(dev) : 256;
         const long long resident = 4LL * cus;
         if (groups > resident) groups = resident;
     }

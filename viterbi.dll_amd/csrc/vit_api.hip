@@ -22,16 +22,10 @@
 
 #include "vit_internal.h"
 
-namespace {
+static thread_local char t_err[256] = "";
+#define set_err vit_set_err
 
-thread_local char t_err[256] = "";
-void set_err(const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(t_err, sizeof t_err, fmt, ap);
-    va_end(ap);
-    if (getenv("VITERBI_AMD_VERBOSE")) fprintf(stderr, "[libviterbi] %s\n", t_err);
-}
+namespace {
 
 // ---- opt-in call log, the analogue of the reference's VIT_WRITE_LOGFILE build -------------------
 // (deconvolve.cpp:568-649, rschecksf.cpp:94-186): VITERBI_AMD_LOG=<path> appends one line per
@@ -68,18 +62,20 @@ struct ScopedCall {
 // ---- process-wide state (written at init only, like deconJumpTarget) -------
 std::once_flag g_once;
 int g_ndev = 0;           // usable gfx950 devices
-int g_device = -1;        // selected device
+int g_device = -1;        // selected device (host-buffer entry points; *_dev calls use the caller's current device)
 int g_cus = 0;
+char g_init_err[160] = "no usable gfx950 (MI355X) HIP device; libviterbi has no CPU path";
 std::atomic<int> g_fault{0};   // reference: exceptCounter / decon_savemode
 std::atomic<int> g_kernel{0};  // 0 auto, 1 wave, 2 packed
 
 void probe_devices() {
-    // Callers are threads (README.md:56), each with its own stream.  ROCclr multiplexes a process's streams
-    // onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels that share a queue run one after the
-    // other: with the default, 16 concurrent deconvolve() callers get 41 k calls/s, with 16 queues 51 k, with
-    // 4 callers 24 k vs 40 k (profiles/r01_vitbench.txt).  Only effective if this is the process's first HIP
-    // call, and never overrides a value the user has set.
-    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    // Callers are threads (README.md:56), each with its own stream.  ROCclr multiplexes a process's streams onto
+    // GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels that share a queue run one after the other, so
+    // a host with many concurrent deconvolve() callers wants more.  That is the host's policy:
+    // the library only touches the environment when VITERBI_AMD_HW_QUEUES explicitly asks it to, and only if this
+    // is early enough (before the process's first HIP call) and GPU_MAX_HW_QUEUES is not set already.
+    if (const char* q = getenv("VITERBI_AMD_HW_QUEUES"))
+        if (atoi(q) > 0) setenv("GPU_MAX_HW_QUEUES", q, 0);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
         (void)hipGetLastError();
@@ -89,23 +85,26 @@ void probe_devices() {
     }
     int want = 0;
     if (const char* e = getenv("VITERBI_AMD_DEVICE")) want = atoi(e);
-    int usable = 0, chosen = -1, first = -1, first_cus = 0;
+    int usable = 0, chosen = -1;
     for (int d = 0; d < n; d++) {
         hipDeviceProp_t pr;
         if (hipGetDeviceProperties(&pr, d) != hipSuccess) continue;
         if (strncmp(pr.gcnArchName, "gfx950", 6) != 0) continue;  // kernels exist for gfx950 only
-        if (first < 0) { first = d; first_cus = pr.multiProcessorCount; }
         if (usable == want) { chosen = d; g_cus = pr.multiProcessorCount; }
         usable++;
     }
-    if (chosen < 0) { chosen = first; g_cus = first_cus; }
     g_ndev = usable;
     g_device = chosen;
+    if (usable > 0 && chosen < 0)  // never fall back silently to another GPU than the one asked for
+        snprintf(g_init_err, sizeof g_init_err, "VITERBI_AMD_DEVICE=%d is out of range: %d usable gfx950 device(s)", want,
+                 usable);
 }
 void ensure_init() { std::call_once(g_once, probe_devices); }
 
 // ---- per-thread context: stream + staging (README.md:56: callers are threads) ----
+// Everything in it belongs to ONE device (`dev`); a thread that comes back with another device gets a fresh one.
 struct ThreadCtx {
+    int dev = -1;
     hipStream_t stream = nullptr;
     void* h_pin = nullptr;   size_t h_cap = 0;   // pinned host staging (mapped: h_pin_dev is its device view)
     void* h_pin_dev = nullptr;
@@ -115,7 +114,7 @@ struct ThreadCtx {
     void* d_ret = nullptr;   size_t dret_cap = 0;
     hipEvent_t scratch_ev = nullptr;  // last use of d_sym8 by a *_dev call on a caller-owned stream
     bool ready = false;
-    ~ThreadCtx() {
+    void release() {
         if (!ready) return;
         // process teardown may already have destroyed the runtime: ignore errors
         if (h_pin) (void)hipHostFree(h_pin);
@@ -125,7 +124,9 @@ struct ThreadCtx {
         if (d_ret) (void)hipFree(d_ret);
         if (scratch_ev) (void)hipEventDestroy(scratch_ev);
         if (stream) (void)hipStreamDestroy(stream);
+        *this = ThreadCtx();
     }
+    ~ThreadCtx() { release(); }
 };
 thread_local ThreadCtx t_ctx;
 
@@ -138,15 +139,25 @@ thread_local ThreadCtx t_ctx;
         }                                                                                  \
     } while (0)
 
-int ctx_prepare() {
+int hip_device_ready() {
     ensure_init();
     if (g_device < 0) {
-        set_err("no usable gfx950 (MI355X) HIP device; libviterbi has no CPU path");
+        set_err("%s", g_init_err);
         return VIT_ERR_NO_DEVICE;
     }
-    HIPCHK(hipSetDevice(g_device));
+    return VIT_OK;
+}
+
+// Makes the calling thread's context usable on device `dev`, which must be the CURRENT device (the exported
+// entry points hold a VitDeviceGuard, so the caller's own current device is restored when they return).
+int ctx_prepare(int dev) {
+    if (t_ctx.ready && t_ctx.dev != dev) {
+        if (t_ctx.stream) (void)hipStreamSynchronize(t_ctx.stream);
+        t_ctx.release();
+    }
     if (!t_ctx.ready) {
         HIPCHK(hipStreamCreateWithFlags(&t_ctx.stream, hipStreamNonBlocking));
+        t_ctx.dev = dev;
         t_ctx.ready = true;
     }
     return VIT_OK;
@@ -173,19 +184,18 @@ int grow_pin(size_t need) {
 
 bool valid_framebits(uint32_t fb) { return fb <= VIT_MAX_FRAMEBITS && (fb & 1u) == 0; }
 
-// the analogue of setupdll.cpp:195-270's dispatcher: choose the kernel for a batch
-bool packed_kernel_selected(const vit_frame_desc* d_desc, uint32_t framebits, uint32_t max_framebits, bool* forced_bad) {
-    const int k = g_kernel.load();
-    (void)d_desc;
-    (void)framebits;
+// the analogue of setupdll.cpp:195-270's dispatcher: choose the kernel for a batch.  `choice` is the value of
+// vit_set_kernel() READ ONCE by the exported entry point (a concurrent vit_set_kernel must not flip the decision
+// between the check that sizes the scratch buffers and the launch).
+bool packed_kernel_selected(int choice, uint32_t max_framebits, bool* forced_bad) {
     const bool pk_ok = vit_pk_supported(max_framebits);  // every even length up to 9216
-    if (forced_bad) *forced_bad = (k == 2 && !pk_ok);
-    return k == 1 ? false : pk_ok;
+    if (forced_bad) *forced_bad = (choice == 2 && !pk_ok);
+    return choice == 1 ? false : pk_ok;
 }
-int launch_decode(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_desc* d_desc, uint32_t framebits,
+int launch_decode(int choice, const uint8_t* d_sym, uint8_t* d_out, const vit_frame_desc* d_desc, uint32_t framebits,
                   uint32_t max_framebits, int64_t nframes, hipStream_t s) {
     bool forced_bad = false;
-    const bool use_pk = packed_kernel_selected(d_desc, framebits, max_framebits, &forced_bad);
+    const bool use_pk = packed_kernel_selected(choice, max_framebits, &forced_bad);
     if (forced_bad) {
         set_err("packed kernel does not support framebits=%u", max_framebits);
         return VIT_ERR_ARG;
@@ -200,10 +210,12 @@ int launch_decode(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_desc* d_
 }
 // Symbols still in the reference ABI's u32 format (deconvolve.cpp:158-165).  The packed kernels read them
 // directly (narrowing fused into their pre-pass); otherwise they are narrowed into `d_scratch8` first.
-int launch_decode_u32(const uint32_t* d_sym32, uint8_t* d_scratch8, uint8_t* d_out, const vit_frame_desc* d_desc,
+bool u32_in_place(int choice, const void* d_sym32, uint32_t max_framebits) {
+    return packed_kernel_selected(choice, max_framebits, nullptr) && (reinterpret_cast<uintptr_t>(d_sym32) & 15u) == 0;
+}
+int launch_decode_u32(int choice, const uint32_t* d_sym32, uint8_t* d_scratch8, uint8_t* d_out, const vit_frame_desc* d_desc,
                       uint32_t framebits, uint32_t max_framebits, int64_t nframes, int64_t nsym, hipStream_t s) {
-    if (packed_kernel_selected(d_desc, framebits, max_framebits, nullptr) &&
-        (reinterpret_cast<uintptr_t>(d_sym32) & 15u) == 0) {
+    if (u32_in_place(choice, d_sym32, max_framebits)) {
         hipError_t e = vit_launch_pk(d_sym32, true, d_out, d_desc, framebits, max_framebits, nframes, s);
         if (e != hipSuccess) {
             set_err("kernel launch failed: %s", hipGetErrorString(e));
@@ -211,20 +223,14 @@ int launch_decode_u32(const uint32_t* d_sym32, uint8_t* d_scratch8, uint8_t* d_o
         }
         return VIT_OK;
     }
+    if (!d_scratch8) {
+        set_err("internal: no scratch buffer for the u32 narrowing");
+        return VIT_ERR_ARG;
+    }
     hipError_t e = vit_launch_pack(d_sym32, d_scratch8, nsym, s);
     if (e != hipSuccess) { set_err("pack launch failed: %s", hipGetErrorString(e)); return VIT_ERR_HIP; }
-    return launch_decode(d_scratch8, d_out, d_desc, framebits, max_framebits, nframes, s);
+    return launch_decode(choice, d_scratch8, d_out, d_desc, framebits, max_framebits, nframes, s);
 }
-
-int hip_device_ready() {
-    ensure_init();
-    if (g_device < 0) {
-        set_err("no usable gfx950 (MI355X) HIP device; libviterbi has no CPU path");
-        return VIT_ERR_NO_DEVICE;
-    }
-    return VIT_OK;
-}
-
 
 // ---- ingest stage: micro-batching of concurrent deconvolve() callers -------------
 // Off by default (window 0): every call then runs on its own thread's stream.  With a window of
@@ -249,7 +255,8 @@ struct Batcher {
     void* d_desc = nullptr; size_t ddesc_cap = 0;
 
     int process(std::vector<BatchReq*>& b) {
-        int rc = ctx_prepare();  // the worker thread has its own stream and buffers
+        VitDeviceGuard guard(g_device);
+        int rc = ctx_prepare(g_device);  // the worker thread has its own stream and buffers
         if (rc != VIT_OK) return rc;
         size_t nsym = 0, nout = 0;
         uint32_t maxfb = 0;
@@ -285,7 +292,7 @@ struct Batcher {
         HIPCHK(hipMemcpyAsync(t_ctx.d_in, pin, nsym * 4, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(d_desc, h_d, desc_bytes, hipMemcpyHostToDevice, s));
         // sym_offset counts symbols: the same table addresses the u32 buffer and its narrowed copy
-        rc = launch_decode_u32((const uint32_t*)t_ctx.d_in, (uint8_t*)t_ctx.d_sym8, (uint8_t*)t_ctx.d_out,
+        rc = launch_decode_u32(g_kernel.load(), (const uint32_t*)t_ctx.d_in, (uint8_t*)t_ctx.d_sym8, (uint8_t*)t_ctx.d_out,
                                (const vit_frame_desc*)d_desc, 0, maxfb, (int64_t)b.size(), (int64_t)nsym, s);
         if (rc != VIT_OK) return rc;
         HIPCHK(hipMemcpyAsync(h_out, t_ctx.d_out, nout, hipMemcpyDeviceToHost, s));
@@ -332,6 +339,40 @@ Batcher* g_batcher = new Batcher();  // intentionally never destroyed (worker ma
 
 }  // namespace
 
+void vit_set_err(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_err, sizeof t_err, fmt, ap);
+    va_end(ap);
+    if (getenv("VITERBI_AMD_VERBOSE")) fprintf(stderr, "[libviterbi] %s\n", t_err);
+}
+
+int vit_device_cus(int dev) {
+    static std::mutex mu;
+    static int cus[64] = {0};
+    if (dev < 0 || dev >= 64) return 256;
+    std::lock_guard<std::mutex> lk(mu);
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
+hipError_t vit_optin_dynamic_lds(const void* const* kernels, int nkernels, int bytes, int dev, uint64_t* done) {
+    static std::mutex mu;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lk(mu);
+    if ((*done >> dev) & 1u) return hipSuccess;
+    for (int i = 0; i < nkernels; i++) {
+        const hipError_t e = hipFuncSetAttribute(kernels[i], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+    }
+    *done |= 1ull << dev;
+    return hipSuccess;
+}
+
 extern "C" {
 
 const char* vit_last_error(void) { return t_err; }
@@ -367,7 +408,9 @@ int GetCPUCaps(void) {
 }
 
 void WakeUpYMM(void) {
-    if (ctx_prepare() != VIT_OK) return;
+    if (hip_device_ready() != VIT_OK) return;
+    VitDeviceGuard guard(g_device);
+    if (ctx_prepare(g_device) != VIT_OK) return;
     (void)grow_pin(65536);
     (void)grow_dev(&t_ctx.d_in, &t_ctx.din_cap, 65536);
     (void)grow_dev(&t_ctx.d_sym8, &t_ctx.d8_cap, 65536);
@@ -393,7 +436,8 @@ int vit_decode_batch_dev(const uint8_t* d_symbols_u8, uint8_t* d_decoded, uint32
         return VIT_ERR_ARG;
     }
     if (framebits == 0 || nframes == 0) return VIT_OK;
-    return launch_decode(d_symbols_u8, d_decoded, nullptr, framebits, framebits, nframes, (hipStream_t)stream);
+    return launch_decode(g_kernel.load(), d_symbols_u8, d_decoded, nullptr, framebits, framebits, nframes,
+                         (hipStream_t)stream);
 }
 
 int vit_decode_batch_dev_u32(const uint32_t* d_symbols_u32, uint8_t* d_decoded, uint32_t framebits,
@@ -405,18 +449,22 @@ int vit_decode_batch_dev_u32(const uint32_t* d_symbols_u32, uint8_t* d_decoded, 
     }
     if (framebits == 0 || nframes == 0) return VIT_OK;
     const size_t nsym = (size_t)nframes * 4u * (framebits + VIT_TAIL);
-    if (packed_kernel_selected(nullptr, framebits, framebits, nullptr) &&
-        (reinterpret_cast<uintptr_t>(d_symbols_u32) & 15u) == 0)  // read in place: no scratch, no extra launch
-        return launch_decode_u32(d_symbols_u32, nullptr, d_decoded, nullptr, framebits, framebits, nframes, (int64_t)nsym,
-                                 (hipStream_t)stream);
-    int rc = ctx_prepare();
+    const int choice = g_kernel.load();
+    if (u32_in_place(choice, d_symbols_u32, framebits))  // read in place: no scratch, no extra launch
+        return launch_decode_u32(choice, d_symbols_u32, nullptr, d_decoded, nullptr, framebits, framebits, nframes,
+                                 (int64_t)nsym, (hipStream_t)stream);
+    // The narrowed symbols go to this thread's scratch buffer ON THE CALLER'S CURRENT DEVICE (the device its
+    // pointers and stream belong to), not on the library's default device.
+    int dev = -1;
+    HIPCHK(hipGetDevice(&dev));
+    int rc = ctx_prepare(dev);
     if (rc != VIT_OK) return rc;
     rc = grow_dev(&t_ctx.d_sym8, &t_ctx.d8_cap, nsym);  // may synchronise the device (hipMalloc)
     if (rc != VIT_OK) return rc;
-    // the narrowed symbols live in this thread's scratch buffer: order its reuse across the caller's streams
+    // order the scratch buffer's reuse across the caller's streams
     if (!t_ctx.scratch_ev) HIPCHK(hipEventCreateWithFlags(&t_ctx.scratch_ev, hipEventDisableTiming));
     else HIPCHK(hipStreamWaitEvent((hipStream_t)stream, t_ctx.scratch_ev, 0));
-    rc = launch_decode_u32(d_symbols_u32, (uint8_t*)t_ctx.d_sym8, d_decoded, nullptr, framebits, framebits, nframes,
+    rc = launch_decode_u32(choice, d_symbols_u32, (uint8_t*)t_ctx.d_sym8, d_decoded, nullptr, framebits, framebits, nframes,
                            (int64_t)nsym, (hipStream_t)stream);
     if (rc != VIT_OK) return rc;
     HIPCHK(hipEventRecord(t_ctx.scratch_ev, (hipStream_t)stream));
@@ -432,7 +480,7 @@ int vit_decode_varlen_dev(const uint8_t* d_symbols_u8, uint8_t* d_decoded, const
         return VIT_ERR_ARG;
     }
     if (nframes == 0 || max_framebits == 0) return VIT_OK;
-    return launch_decode(d_symbols_u8, d_decoded, d_desc, 0, max_framebits, nframes, (hipStream_t)stream);
+    return launch_decode(g_kernel.load(), d_symbols_u8, d_decoded, d_desc, 0, max_framebits, nframes, (hipStream_t)stream);
 }
 
 void vit_sort_descs(vit_frame_desc* h_desc, int64_t nframes) {
@@ -447,15 +495,17 @@ int vit_decode_batch_host(const uint8_t* h_symbols_u8, uint8_t* h_decoded, uint3
         return VIT_ERR_ARG;
     }
     if (framebits == 0 || nframes == 0) return VIT_OK;
-    int rc = ctx_prepare();
+    int rc = hip_device_ready();
     if (rc != VIT_OK) return rc;
+    VitDeviceGuard guard(g_device);
+    if ((rc = ctx_prepare(g_device)) != VIT_OK) return rc;
     const size_t in_sz = (size_t)nframes * 4u * (framebits + VIT_TAIL);
     const size_t out_sz = (size_t)nframes * ((framebits + 7u) >> 3);
     if ((rc = grow_dev(&t_ctx.d_sym8, &t_ctx.d8_cap, in_sz)) != VIT_OK) return rc;
     if ((rc = grow_dev(&t_ctx.d_out, &t_ctx.dout_cap, out_sz)) != VIT_OK) return rc;
     HIPCHK(hipMemcpyAsync(t_ctx.d_sym8, h_symbols_u8, in_sz, hipMemcpyHostToDevice, t_ctx.stream));
-    rc = launch_decode((const uint8_t*)t_ctx.d_sym8, (uint8_t*)t_ctx.d_out, nullptr, framebits, framebits, nframes,
-                       t_ctx.stream);
+    rc = launch_decode(g_kernel.load(), (const uint8_t*)t_ctx.d_sym8, (uint8_t*)t_ctx.d_out, nullptr, framebits, framebits,
+                       nframes, t_ctx.stream);
     if (rc != VIT_OK) return rc;
     HIPCHK(hipMemcpyAsync(h_decoded, t_ctx.d_out, out_sz, hipMemcpyDeviceToHost, t_ctx.stream));
     HIPCHK(hipStreamSynchronize(t_ctx.stream));
@@ -485,7 +535,9 @@ static int deconvolve_impl(unsigned int framebits, unsigned int* symbols, unsign
         }
         return 0;
     }
-    if (ctx_prepare() != VIT_OK) return 1;
+    if (hip_device_ready() != VIT_OK) return 1;
+    VitDeviceGuard guard(g_device);
+    if (ctx_prepare(g_device) != VIT_OK) return 1;
     const size_t nsym = 4u * ((size_t)framebits + VIT_TAIL);
     const size_t out_sz = (framebits + 7u) >> 3;
     int rc;
@@ -505,7 +557,7 @@ static int deconvolve_impl(unsigned int framebits, unsigned int* symbols, unsign
     // kernel narrows the symbols first.)
     unsigned char* h_out = (unsigned char*)t_ctx.h_pin + nsym * 4;
     memcpy(t_ctx.h_pin, symbols, nsym * 4);
-    if (launch_decode_u32((const uint32_t*)t_ctx.h_pin_dev, (uint8_t*)t_ctx.d_sym8, (uint8_t*)t_ctx.h_pin_dev + nsym * 4,
+    if (launch_decode_u32(g_kernel.load(), (const uint32_t*)t_ctx.h_pin_dev, (uint8_t*)t_ctx.d_sym8, (uint8_t*)t_ctx.h_pin_dev + nsym * 4,
                           nullptr, framebits, framebits, 1, (int64_t)nsym, t_ctx.stream) != VIT_OK) {
         g_fault.store(1);
         return 1;
@@ -543,7 +595,7 @@ int vit_dabplus_superframes_dev(const uint8_t* d_symbols_u8, uint8_t* d_work, ui
         return VIT_ERR_ARG;
     }
     if (nsf == 0) return VIT_OK;
-    int rc = launch_decode(d_symbols_u8, d_work, nullptr, (uint32_t)framebits, (uint32_t)framebits, 5 * nsf,
+    int rc = launch_decode(g_kernel.load(), d_symbols_u8, d_work, nullptr, (uint32_t)framebits, (uint32_t)framebits, 5 * nsf,
                            (hipStream_t)stream);
     if (rc != VIT_OK) return rc;
     return vit_rs_batch_dev(d_work, d_rs_out, d_ret, RSDims, nsf, stream);
@@ -556,8 +608,10 @@ int vit_rs_batch_host(const uint8_t* h_p, uint8_t* h_out, int32_t* h_ret, uint32
     }
     if (nsf == 0) return VIT_OK;
     if (RSDims == 0) { memset(h_ret, 0, (size_t)nsf * sizeof(int32_t)); return VIT_OK; }
-    int rc = ctx_prepare();
+    int rc = hip_device_ready();
     if (rc != VIT_OK) return rc;
+    VitDeviceGuard guard(g_device);
+    if ((rc = ctx_prepare(g_device)) != VIT_OK) return rc;
     const size_t in_sz = (size_t)nsf * 120u * RSDims, out_sz = (size_t)nsf * 110u * RSDims;
     if ((rc = grow_dev(&t_ctx.d_in, &t_ctx.din_cap, in_sz)) != VIT_OK) return rc;
     if ((rc = grow_dev(&t_ctx.d_out, &t_ctx.dout_cap, out_sz)) != VIT_OK) return rc;
@@ -592,7 +646,9 @@ static int rscheck_impl(unsigned char* p, unsigned int RSDims, unsigned char* ou
     // Zero-copy like deconvolve(): the 120*RSDims input bytes, the caller's current output bytes (columns at
     // and after the first failure must keep them) and the return value live in the thread's mapped pinned
     // buffer; the kernel reads and writes host memory directly - one launch, one sync, no hipMemcpy.
-    if (ctx_prepare() != VIT_OK) return -1;
+    if (hip_device_ready() != VIT_OK) return -1;
+    VitDeviceGuard guard(g_device);
+    if (ctx_prepare(g_device) != VIT_OK) return -1;
     const size_t in_sz = 120u * (size_t)RSDims, out_sz = 110u * (size_t)RSDims;
     const size_t in_pad = (in_sz + 15u) & ~(size_t)15u, out_pad = (out_sz + 15u) & ~(size_t)15u;
     if (grow_pin(in_pad + out_pad + 64) != VIT_OK) {

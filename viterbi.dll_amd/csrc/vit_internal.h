@@ -30,3 +30,26 @@ hipError_t vit_launch_pack(const uint32_t* d_sym32, uint8_t* d_sym8, int64_t nsy
 // RS(120,110) superframe check, one lane per column.
 hipError_t rs_launch(const uint8_t* d_p, uint8_t* d_out, int32_t* d_ret, uint32_t rsdims,
                      int64_t nsf, hipStream_t stream);
+
+// ---- host-side helpers shared by the TUs -------------------------------------------------------
+// per-thread error text behind vit_last_error() (printf-style)
+void vit_set_err(const char* fmt, ...);
+// CU count of a HIP device, cached (persistent grids are sized by it)
+int vit_device_cus(int dev);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: opt the kernels in once per (device, caller).
+// `done` is the caller's bitmask of devices already handled (guarded by an internal mutex).
+hipError_t vit_optin_dynamic_lds(const void* const* kernels, int nkernels, int bytes, int dev, uint64_t* done);
+// Restores the calling thread's current HIP device on scope exit (library calls must not leave it changed).
+struct VitDeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit VitDeviceGuard(int want) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (want >= 0 && prev != want && hipSetDevice(want) == hipSuccess) changed = true;
+    }
+    ~VitDeviceGuard() {
+        if (changed && prev >= 0) (void)hipSetDevice(prev);
+    }
+    VitDeviceGuard(const VitDeviceGuard&) = delete;
+    VitDeviceGuard& operator=(const VitDeviceGuard&) = delete;
+};

@@ -562,9 +562,9 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
                 fbits[k] = desc[f].framebits;
                 soff[k] = desc[f].sym_offset;
                 ooff[k] = desc[f].out_offset;
-                // a descriptor the launch was not sized for (longer than max_framebits, or odd) is
-                // skipped rather than allowed to run off the LDS layout
-                if (fbits[k] > lay.maxfb || (fbits[k] & 1u)) fbits[k] = 0;
+                // a descriptor the launch was not sized for (longer than max_framebits, or odd) is skipped rather
+                // than allowed to run off the LDS layout; so is one whose symbols are not dword aligned
+                if (fbits[k] > lay.maxfb || (fbits[k] & 1u) || (soff[k] & 3u)) fbits[k] = 0;
             } else {
                 fbits[k] = framebits_uniform;
                 soff[k] = (size_t)f * 4u * (framebits_uniform + VIT_TAIL);
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
                     fbits[k] = desc[f].framebits;
                     soff[k] = desc[f].sym_offset;
                     ooff[k] = desc[f].out_offset;
-                    if (fbits[k] > lay.maxfb || (fbits[k] & 1u)) fbits[k] = 0;  // not what the launch was sized for
+                    if (fbits[k] > lay.maxfb || (fbits[k] & 1u) || (soff[k] & 3u)) fbits[k] = 0;  // not what the launch was sized for / misaligned
                 } else {
                     fbits[k] = framebits_uniform;
                     soff[k] = (size_t)f * 4u * (framebits_uniform + VIT_TAIL);
@@ -888,20 +888,6 @@ bool sort_enabled() {
     return on;
 }
 
-// CUs of a device (persistent grids are sized by it), cached per device
-static int device_cus(int dev) {
-    static std::mutex mu;
-    static int cus[64] = {0};
-    if (dev < 0 || dev >= 64) return 256;
-    std::lock_guard<std::mutex> lk(mu);
-    if (cus[dev] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus[dev] = n;
-    }
-    return cus[dev];
-}
-
 hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, const vit_frame_desc* d_desc,
                          uint32_t framebits, uint32_t max_framebits, int64_t nframes, hipStream_t stream) {
     const uint8_t* d_sym = static_cast<const uint8_t*>(d_symbols);
@@ -911,21 +897,13 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
     hipError_t e;
     int dev = 0;
     if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
-    // the dynamic-LDS opt-in is per device: once per (device, kernel)
-    {
-        static std::mutex mu;
-        static uint64_t done = 0;
-        std::lock_guard<std::mutex> lk(mu);
-        if (dev >= 0 && dev < 64 && !((done >> dev) & 1u)) {
-            const void* ks[4] = {reinterpret_cast<const void*>(vit_pk_kernel<false>),
-                                 reinterpret_cast<const void*>(vit_pk_kernel<true>),
-                                 reinterpret_cast<const void*>(vit_pk_long_kernel<false>),
-                                 reinterpret_cast<const void*>(vit_pk_long_kernel<true>)};
-            for (const void* k : ks)
-                if ((e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess)
-                    return e;
-            done |= 1ull << dev;
-        }
+    {  // the dynamic-LDS opt-in is per device
+        static uint64_t optin_done = 0;
+        const void* ks[4] = {reinterpret_cast<const void*>(vit_pk_kernel<false>),
+                             reinterpret_cast<const void*>(vit_pk_kernel<true>),
+                             reinterpret_cast<const void*>(vit_pk_long_kernel<false>),
+                             reinterpret_cast<const void*>(vit_pk_long_kernel<true>)};
+        if ((e = vit_optin_dynamic_lds(ks, 4, 160 * 1024, dev, &optin_done)) != hipSuccess) return e;
     }
     const long long groups = (nframes + 3) / 4;
     if (groups > 0x7FFFFFFFLL) return hipErrorInvalidValue;
@@ -945,7 +923,7 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
     {
         u32 per_cu = (160u * 1024u) / lay.total;
         if (per_cu > 16u) per_cu = 16u;  // 4 waves per SIMD (launch bounds)
-        grid = (long long)per_cu * device_cus(dev);
+        grid = (long long)per_cu * vit_device_cus(dev);
         if (grid > groups) grid = groups;
     }
     const bool need_counter = is_long || VIT_PERSIST == 2;

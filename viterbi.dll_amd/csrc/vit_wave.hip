@@ -44,7 +44,9 @@ __global__ __launch_bounds__(64) void vit_wave_kernel(const uint8_t* __restrict_
             framebits = desc[f].framebits;
             sym_off = desc[f].sym_offset;
             out_off = desc[f].out_offset;
-            if (framebits > max_framebits) continue;  // the launch's LDS was not sized for it: skipped
+            // the launch's LDS was not sized for it, an odd length (not a valid frame) or symbols that are not
+            // dword aligned: skipped, output untouched
+            if (framebits > max_framebits || (framebits & 1u) || (sym_off & 3u)) continue;
         } else {
             sym_off = (size_t)f * 4u * (framebits + VIT_TAIL);
             out_off = (size_t)f * ((framebits + 7u) >> 3);
@@ -108,13 +110,12 @@ hipError_t vit_launch_wave(const uint8_t* d_sym, uint8_t* d_out, const vit_frame
                            hipStream_t stream) {
     if (nframes <= 0) return hipSuccess;
     const size_t lds = (size_t)(max_framebits + VIT_TAIL) * 8u;
-    static std::once_flag attr_once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(attr_once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(vit_wave_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    });
-    if (attr_err != hipSuccess) return attr_err;
+    static uint64_t optin_done = 0;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const void* ks[1] = {reinterpret_cast<const void*>(vit_wave_kernel)};
+    if ((e = vit_optin_dynamic_lds(ks, 1, 80 * 1024, dev, &optin_done)) != hipSuccess) return e;
     const long long grid = nframes < (1 << 20) ? nframes : (1 << 20);
     hipLaunchKernelGGL(vit_wave_kernel, dim3((unsigned)grid), dim3(64), lds, stream, d_sym, d_out, d_desc,
                        framebits, max_framebits, (long long)nframes);

@@ -65,6 +65,10 @@ def test_no_device_fails_loudly_without_cpu_fallback(V):
         V.decode_batch_host(np.zeros((1, 4 * 774), np.uint8), 768)
     # framebits == 0 is a successful no-op like the reference's C path
     assert V.lib().deconvolve(0, None, 0, None) == 0
+    # the multi-GPU entry: same loud failure, before RCCL is even looked for
+    devs = (C.c_int * 2)(0, 1)
+    assert V.lib().vit_decode_stream_multi(None, None, 768, 16, devs, 2, 4, -1, 0, None) == 2  # VIT_ERR_NO_DEVICE
+    assert "gfx950" in V.last_error()
 
 
 def test_call_log_env(tmp_path):

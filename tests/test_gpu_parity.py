@@ -254,7 +254,12 @@ def test_varlen_device_sort_mixed_and_invalid(V, O, torch_cuda, kernel):
         torch.cuda.synchronize()
     finally:
         V.set_kernel(old)
-    assert np.array_equal(d_out.cpu().numpy(), want)
+    got = d_out.cpu().numpy()
+    if not np.array_equal(got, want):
+        bad = [(i, fbs[i]) for i, d in enumerate(desc)
+               if not np.array_equal(got[int(d["out_offset"]):int(d["out_offset"]) + (fbs[i] + 7) // 8],
+                                     want[int(d["out_offset"]):int(d["out_offset"]) + (fbs[i] + 7) // 8])]
+        raise AssertionError("frames (index, framebits) that differ: %s" % bad[:12])
     assert np.array_equal(d_desc.cpu().numpy(), desc.view(np.uint8))
     if kernel:
         return

@@ -152,15 +152,21 @@ int vit_rs_batch_host(const uint8_t *h_p, uint8_t *h_out, int32_t *h_ret,
 int vit_dabplus_superframes_dev(const uint8_t *d_symbols_u8, uint8_t *d_work, uint8_t *d_rs_out,
                                 int32_t *d_ret, uint32_t RSDims, int64_t nsf, void *stream);
 
-/* Ingest stage for concurrent callers of deconvolve(): with a window > 0, calls arriving within
- * `microseconds` of each other (from any threads) are decoded by ONE pack + ONE decode launch on a
- * worker thread; each caller still blocks until its own frame is done.  0 (default) = every call on
- * its own stream.  Returns the previous window. */
+/* Ingest stage for concurrent callers of deconvolve().  Off by default (window 0): every call runs on its own
+ * thread's stream.  With a window > 0 the stage is ADAPTIVE: a call joins a shared launch only while at least
+ * `min_callers` (default 8) deconvolve() calls are in flight in the process; below that it takes the direct
+ * path, so a handful of threads never wait for each other.  Batched calls park their request; a worker thread
+ * closes the batch as soon as every caller that chose to batch has arrived - `microseconds` is only the upper
+ * bound of that wait - and runs ONE variable-length decode launch for all of them; each caller still blocks
+ * until its own frame is done.  Both setters return the previous value. */
 int vit_set_batch_window_us(int microseconds);
+int vit_set_batch_min_callers(int min_callers);
 
-/* Kernel selection for experiments/tests: 0 = auto, 1 = wave-per-frame
- * reference kernel, 2 = packed 4-frames-per-wave kernel.  Returns the old
- * value.  Affects later vit_decode_* calls of the whole process. */
+/* Kernel selection (the analogue of the reference's dispatcher, setupdll.cpp:195-270):
+ *   0 = auto: launches of up to 2048 frames (they cannot fill the chip) take the latency kernel - one
+ *       frame per wavefront, ~20 us per FIC frame -, larger ones the packed throughput kernel;
+ *   1 = wave-per-frame cross-check kernel, 2 = packed 4-frames-per-wave kernel, 3 = latency kernel.
+ * Returns the old value.  Affects later vit_decode_* / deconvolve calls of the whole process. */
 int vit_set_kernel(int which);
 
 /* ------------------------------------------------------------------------ *

@@ -26,7 +26,7 @@ def test_golden_fixtures_on_gpu(V, torch_cuda):
         sym = np.frombuffer(base64.b64decode(case["sym_b64"]), np.uint8)
         want = np.frombuffer(bytes.fromhex(case["out_hex"]), np.uint8)
         assert sym.size == 4 * (fb + 6)
-        for kernel in (1, 2):
+        for kernel in (1, 2, 3):
             old = V.set_kernel(kernel)
             try:
                 d_out = torch.zeros((fb + 7) // 8, dtype=torch.uint8, device="cuda")

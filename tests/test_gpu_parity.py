@@ -9,8 +9,8 @@ pytestmark = pytest.mark.gpu
 
 import os
 
-# 1 = wave-per-frame kernel, 2 = packed 4-frames-per-wave kernel
-KERNELS = [int(k) for k in os.environ.get("VIT_TEST_KERNELS", "1,2").split(",")]
+# 1 = wave-per-frame kernel, 2 = packed 4-frames-per-wave kernel, 3 = latency kernel (one frame per wave, DPP)
+KERNELS = [int(k) for k in os.environ.get("VIT_TEST_KERNELS", "1,2,3").split(",")]
 
 
 def _gpu_decode(V, torch, sym, framebits, kernel):
@@ -150,10 +150,17 @@ def test_deconvolve_micro_batching(V, O, torch_cuda):
 
     old = V.set_batch_window_us(200)
     try:
-        th = [threading.Thread(target=work, args=(i,)) for i in range(len(lens))]
-        [t.start() for t in th]
-        [t.join() for t in th]
-        rc, got = V.deconvolve(770, O.uniform_symbols(O.sym_len(770), seed=1).astype(np.uint32))  # not batched
+        # min_callers 2: every overlapping pair of calls shares a launch; 8 (the default): only while all eight
+        # threads are inside deconvolve() at once; 100: never (the adaptive stage stays on the direct path)
+        for min_callers in (2, 8, 100):
+            old_min = V.set_batch_min_callers(min_callers)
+            try:
+                th = [threading.Thread(target=work, args=(i,)) for i in range(len(lens))]
+                [t.start() for t in th]
+                [t.join() for t in th]
+            finally:
+                V.set_batch_min_callers(old_min)
+        rc, got = V.deconvolve(770, O.uniform_symbols(O.sym_len(770), seed=1).astype(np.uint32))  # alone: never batched
         assert rc == 0
     finally:
         V.set_batch_window_us(old)
@@ -184,7 +191,7 @@ def test_u32_ingest_path(V, O, torch_cuda, framebits, n):
         assert np.array_equal(d_out.cpu().numpy(), want), (kernel, shift)
 
 
-@pytest.mark.parametrize("kernel", [0, 1, 2])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3])
 def test_varlen_batch(V, O, torch_cuda, kernel):
     """BASELINE config 3 in small: framebits = 96*m, m in 3..72, descriptor table (+ lengths that are
     not multiples of 8: a partial last byte per frame)"""
@@ -224,7 +231,7 @@ def test_random_lengths_and_batch_sizes(V, O, torch_cuda):
         assert np.array_equal(got, want), "framebits=%d n=%d" % (fb, n)
 
 
-@pytest.mark.parametrize("kernel", [0, 1, 2])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3])
 def test_varlen_device_sort_mixed_and_invalid(V, O, torch_cuda, kernel):
     """the launcher length-sorts a copy of the table on the device (csrc/vit_sort.hip): a few thousand mixed
     lengths incl. long (spilled) frames, many equal keys, and descriptors the launch was not sized for --

@@ -113,7 +113,7 @@ int main(int argc, char** argv) {
     // 3. concurrent callers
     for (int window : {0, 50}) {
         set_window(window);
-        for (int nt : {1, 4, 16}) {
+        for (int nt : {1, 4, 8, 16, 32}) {
             std::vector<std::thread> th;
             const double t0 = now_s();
             for (int t = 0; t < nt; t++)
@@ -123,7 +123,8 @@ int main(int argc, char** argv) {
                 });
             for (auto& x : th) x.join();
             const double dt = now_s() - t0;
-            printf("threads %2d  batch window %2d us: %9.0f calls/s\n", nt, window, nt * (double)loops / dt);
+            printf("threads %2d  batch window %2d us%s: %9.0f calls/s\n", nt, window,
+                   window ? " (adaptive: engages at >= 8 calls in flight)" : "", nt * (double)loops / dt);
         }
     }
     set_window(0);

@@ -20,7 +20,8 @@ TAIL = 6
 
 EXPORTS = [
     "deconvolve", "initialize", "RScheckSuperframe", "RSCheckSuperframe", "GetCPUCaps", "WakeUpYMM",
-    "vit_last_error", "vit_device_count", "vit_set_kernel", "vit_set_batch_window_us", "vit_decode_batch_dev",
+    "vit_last_error", "vit_device_count", "vit_set_kernel", "vit_set_batch_window_us", "vit_set_batch_min_callers",
+    "vit_decode_batch_dev",
     "vit_decode_batch_dev_u32", "vit_decode_varlen_dev", "vit_pack_symbols_dev", "vit_sort_descs",
     "vit_decode_batch_host", "vit_rs_batch_dev", "vit_rs_batch_host", "vit_dabplus_superframes_dev",
     "vit_decode_stream_multi",
@@ -70,6 +71,7 @@ def lib():
         L.vit_last_error.restype = C.c_char_p
         L.vit_set_kernel.argtypes = [C.c_int]
         L.vit_set_batch_window_us.argtypes = [C.c_int]
+        L.vit_set_batch_min_callers.argtypes = [C.c_int]
         L.vit_decode_batch_dev.argtypes = [vp, vp, C.c_uint32, C.c_int64, vp]
         L.vit_decode_batch_dev_u32.argtypes = [vp, vp, C.c_uint32, C.c_int64, vp]
         L.vit_decode_varlen_dev.argtypes = [vp, vp, vp, C.c_int64, C.c_uint32, vp]
@@ -122,6 +124,10 @@ def set_kernel(which):
 
 def set_batch_window_us(us):
     return int(lib().vit_set_batch_window_us(int(us)))
+
+
+def set_batch_min_callers(n):
+    return int(lib().vit_set_batch_min_callers(int(n)))
 
 
 def deconvolve(framebits, symbols, unused=0, decoded=None):

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libviterbi.so")
-SOURCES = ["vit_api.hip", "vit_wave.hip", "vit_pk.hip", "vit_sort.hip", "rs_kernels.hip", "vit_multi.hip"]
+SOURCES = ["vit_api.hip", "vit_wave.hip", "vit_pk.hip", "vit_sort.hip", "rs_kernels.hip", "vit_multi.hip", "vit_lat.hip"]
 DEPS = SOURCES + ["vit_internal.h", "exports.map"]
 
 

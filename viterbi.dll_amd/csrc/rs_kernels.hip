@@ -373,7 +373,7 @@ __device__ __forceinline__ void copy_linear(uint8_t* dst, const uint8_t* src, ui
 // (second launch bound: 4 waves per SIMD = 4 workgroups per CU, which is what the 40 KB of LDS allow)
 __global__ __launch_bounds__(RS_THREADS, 4) void rs_kernel(const uint8_t* __restrict__ p, uint8_t* __restrict__ out,
                                                         int32_t* __restrict__ ret, uint32_t rsdims,
-                                                        long long nsf) {
+                                                        long long nsf, int host_polls_ret) {
     __shared__ __attribute__((aligned(16))) uint8_t cw[NCW * RS_THREADS];  // [superframe][row][column]
     __shared__ __attribute__((aligned(16))) uint32_t gtab[256 * 4];
     __shared__ uint8_t ato[768];
@@ -466,8 +466,15 @@ __global__ __launch_bounds__(RS_THREADS, 4) void rs_kernel(const uint8_t* __rest
                 atomicAdd(&s_sum[lsf], res);
             }
         }
+        // single-call path (RScheckSuperframe): the host spins on ret[0] in its mapped buffer instead of waiting for the
+        // end-of-kernel signal, so every output byte must be visible system-wide before the return value is
+        if (host_polls_ret) __threadfence_system();
         __syncthreads();
-        if (tid < nloc) ret[sf0 + tid] = s_minfail[tid] != NOFAIL ? -1 : s_sum[tid];
+        if (tid < nloc) {
+            const int32_t r = s_minfail[tid] != NOFAIL ? -1 : s_sum[tid];
+            if (host_polls_ret) __hip_atomic_store(&ret[sf0 + tid], r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            else ret[sf0 + tid] = r;
+        }
         __syncthreads();
     }
 }
@@ -475,8 +482,9 @@ __global__ __launch_bounds__(RS_THREADS, 4) void rs_kernel(const uint8_t* __rest
 }  // namespace
 
 hipError_t rs_launch(const uint8_t* d_p, uint8_t* d_out, int32_t* d_ret, uint32_t rsdims, int64_t nsf,
-                     hipStream_t stream) {
+                     hipStream_t stream, bool host_polls_ret) {
     if (nsf <= 0 || rsdims == 0) return hipSuccess;
+    if (host_polls_ret && (nsf != 1 || rsdims > RS_THREADS)) return hipErrorInvalidValue;
     const uint32_t spb = rsdims <= RS_THREADS ? RS_THREADS / rsdims : 1u;
     long long groups = (nsf + spb - 1) / spb;
     if (groups > (1 << 20)) groups = 1 << 20;
@@ -489,7 +497,7 @@ hipError_t rs_launch(const uint8_t* d_p, uint8_t* d_out, int32_t* d_ret, uint32_
     }
     if (rsdims <= RS_THREADS)
         hipLaunchKernelGGL(rs_kernel, dim3((unsigned)groups), dim3(RS_THREADS), 0, stream, d_p, d_out, d_ret, rsdims,
-                           (long long)nsf);
+                           (long long)nsf, host_polls_ret ? 1 : 0);
     else
         hipLaunchKernelGGL(rs_kernel_wide, dim3((unsigned)groups), dim3(RS_THREADS), 0, stream, d_p, d_out, d_ret,
                            rsdims, (long long)nsf);

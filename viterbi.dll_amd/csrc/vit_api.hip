@@ -66,7 +66,7 @@ int g_device = -1;        // selected device (host-buffer entry points; *_dev ca
 int g_cus = 0;
 char g_init_err[160] = "no usable gfx950 (MI355X) HIP device; libviterbi has no CPU path";
 std::atomic<int> g_fault{0};   // reference: exceptCounter / decon_savemode
-std::atomic<int> g_kernel{0};  // 0 auto, 1 wave, 2 packed
+std::atomic<int> g_kernel{0};  // 0 auto, 1 wave, 2 packed, 3 latency
 
 void probe_devices() {
     // Callers are threads (README.md:56), each with its own stream.  ROCclr multiplexes a process's streams onto
@@ -113,6 +113,7 @@ struct ThreadCtx {
     void* d_out = nullptr;   size_t dout_cap = 0;
     void* d_ret = nullptr;   size_t dret_cap = 0;
     hipEvent_t scratch_ev = nullptr;  // last use of d_sym8 by a *_dev call on a caller-owned stream
+    uint32_t seq = 0;                 // completion sequence number of the single-call latency path
     bool ready = false;
     void release() {
         if (!ready) return;
@@ -187,36 +188,45 @@ bool valid_framebits(uint32_t fb) { return fb <= VIT_MAX_FRAMEBITS && (fb & 1u) 
 // the analogue of setupdll.cpp:195-270's dispatcher: choose the kernel for a batch.  `choice` is the value of
 // vit_set_kernel() READ ONCE by the exported entry point (a concurrent vit_set_kernel must not flip the decision
 // between the check that sizes the scratch buffers and the launch).
-bool packed_kernel_selected(int choice, uint32_t max_framebits, bool* forced_bad) {
-    const bool pk_ok = vit_pk_supported(max_framebits);  // every even length up to 9216
-    if (forced_bad) *forced_bad = (choice == 2 && !pk_ok);
-    return choice == 1 ? false : pk_ok;
+enum { K_AUTO = 0, K_WAVE = 1, K_PACKED = 2, K_LATENCY = 3 };
+// which kernel runs a batch: the explicit choice, or for K_AUTO the latency kernel for launches that cannot fill
+// the chip (<= VIT_LAT_MAX_FRAMES wavefronts) and the packed kernel otherwise
+int pick_kernel(int choice, uint32_t max_framebits, int64_t nframes) {
+    if (choice == K_WAVE || choice == K_LATENCY) return choice;
+    if (choice == K_AUTO && nframes <= VIT_LAT_MAX_FRAMES) {  // small launch: does it fit the latency kernel's residency?
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && nframes <= vit_lat_capacity(max_framebits, dev)) return K_LATENCY;
+    }
+    return vit_pk_supported(max_framebits) ? K_PACKED : (choice == K_PACKED ? -1 : K_WAVE);
 }
 int launch_decode(int choice, const uint8_t* d_sym, uint8_t* d_out, const vit_frame_desc* d_desc, uint32_t framebits,
                   uint32_t max_framebits, int64_t nframes, hipStream_t s) {
-    bool forced_bad = false;
-    const bool use_pk = packed_kernel_selected(choice, max_framebits, &forced_bad);
-    if (forced_bad) {
+    const int k = pick_kernel(choice, max_framebits, nframes);
+    if (k < 0) {
         set_err("packed kernel does not support framebits=%u", max_framebits);
         return VIT_ERR_ARG;
     }
-    hipError_t e = use_pk ? vit_launch_pk(d_sym, false, d_out, d_desc, framebits, max_framebits, nframes, s)
-                          : vit_launch_wave(d_sym, d_out, d_desc, framebits, max_framebits, nframes, s);
+    hipError_t e = k == K_PACKED    ? vit_launch_pk(d_sym, false, d_out, d_desc, framebits, max_framebits, nframes, s)
+                   : k == K_LATENCY ? vit_launch_lat(d_sym, false, d_out, d_desc, framebits, max_framebits, nframes, s)
+                                    : vit_launch_wave(d_sym, d_out, d_desc, framebits, max_framebits, nframes, s);
     if (e != hipSuccess) {
         set_err("kernel launch failed: %s", hipGetErrorString(e));
         return VIT_ERR_HIP;
     }
     return VIT_OK;
 }
-// Symbols still in the reference ABI's u32 format (deconvolve.cpp:158-165).  The packed kernels read them
-// directly (narrowing fused into their pre-pass); otherwise they are narrowed into `d_scratch8` first.
-bool u32_in_place(int choice, const void* d_sym32, uint32_t max_framebits) {
-    return packed_kernel_selected(choice, max_framebits, nullptr) && (reinterpret_cast<uintptr_t>(d_sym32) & 15u) == 0;
+// Symbols still in the reference ABI's u32 format (deconvolve.cpp:158-165).  The packed and the latency kernel
+// read them directly (narrowing fused into their symbol loads); otherwise they are narrowed into `d_scratch8` first.
+bool u32_in_place(int choice, const void* d_sym32, uint32_t max_framebits, int64_t nframes) {
+    const int k = pick_kernel(choice, max_framebits, nframes);
+    return (k == K_PACKED || k == K_LATENCY) && (reinterpret_cast<uintptr_t>(d_sym32) & 15u) == 0;
 }
 int launch_decode_u32(int choice, const uint32_t* d_sym32, uint8_t* d_scratch8, uint8_t* d_out, const vit_frame_desc* d_desc,
                       uint32_t framebits, uint32_t max_framebits, int64_t nframes, int64_t nsym, hipStream_t s) {
-    if (u32_in_place(choice, d_sym32, max_framebits)) {
-        hipError_t e = vit_launch_pk(d_sym32, true, d_out, d_desc, framebits, max_framebits, nframes, s);
+    if (u32_in_place(choice, d_sym32, max_framebits, nframes)) {
+        const int k = pick_kernel(choice, max_framebits, nframes);
+        hipError_t e = k == K_PACKED ? vit_launch_pk(d_sym32, true, d_out, d_desc, framebits, max_framebits, nframes, s)
+                                     : vit_launch_lat(d_sym32, true, d_out, d_desc, framebits, max_framebits, nframes, s);
         if (e != hipSuccess) {
             set_err("kernel launch failed: %s", hipGetErrorString(e));
             return VIT_ERR_HIP;
@@ -249,6 +259,9 @@ struct Batcher {
     std::condition_variable cv_work, cv_done;
     std::vector<BatchReq*> q;
     std::atomic<int> window_us{0};
+    std::atomic<int> min_callers{8};  // batching engages only while at least this many deconvolve() calls are in flight
+    std::atomic<int> inflight{0};     // deconvolve() calls currently executing (any path)
+    int committed = 0;                // callers that chose the batch path and are not in a batch yet (under mu)
     bool started = false;
     static constexpr size_t MAX_BATCH = 256;
     std::vector<vit_frame_desc> h_desc;
@@ -308,8 +321,12 @@ struct Batcher {
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv_work.wait(lk, [&] { return !q.empty(); });
+                // The window is an upper bound, not a delay: the batch closes as soon as every caller that has
+                // chosen the batch path has arrived (`committed` counts them from their decision on).
                 const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us.load());
-                while (q.size() < MAX_BATCH && cv_work.wait_until(lk, deadline) != std::cv_status::timeout) {}
+                while (q.size() < MAX_BATCH && (int)q.size() < committed &&
+                       cv_work.wait_until(lk, deadline) != std::cv_status::timeout) {}
+                committed -= (int)q.size();
                 batch.swap(q);
             }
             const int rc = process(batch);
@@ -322,7 +339,16 @@ struct Batcher {
         }
     }
 
-    int submit(uint32_t framebits, const unsigned int* symbols, unsigned char* out) {
+    // A caller takes the batch path only while enough calls are in flight to make a shared launch pay: with a
+    // handful of threads every call keeps its own stream and never waits for anybody (profiles/r02_vitbench.txt).
+    bool should_batch() {
+        if (window_us.load(std::memory_order_relaxed) <= 0) return false;
+        if (inflight.load(std::memory_order_relaxed) < min_callers.load(std::memory_order_relaxed)) return false;
+        std::lock_guard<std::mutex> lk(mu);
+        committed++;
+        return true;
+    }
+    int submit(uint32_t framebits, const unsigned int* symbols, unsigned char* out) {  // after should_batch() == true
         BatchReq r{framebits, symbols, out, VIT_ERR_HIP, false};
         std::unique_lock<std::mutex> lk(mu);
         if (!started) {
@@ -334,6 +360,11 @@ struct Batcher {
         cv_done.wait(lk, [&] { return r.done; });
         return r.rc;
     }
+};
+struct InflightGuard {
+    std::atomic<int>& n;
+    explicit InflightGuard(std::atomic<int>& c) : n(c) { n.fetch_add(1, std::memory_order_relaxed); }
+    ~InflightGuard() { n.fetch_sub(1, std::memory_order_relaxed); }
 };
 Batcher* g_batcher = new Batcher();  // intentionally never destroyed (worker may outlive static dtors)
 
@@ -388,8 +419,13 @@ int vit_set_batch_window_us(int microseconds) {
     return g_batcher->window_us.exchange(microseconds);
 }
 
+int vit_set_batch_min_callers(int n) {
+    if (n < 1) n = 1;
+    return g_batcher->min_callers.exchange(n);
+}
+
 int vit_set_kernel(int which) {
-    if (which < 0 || which > 2) which = 0;
+    if (which < K_AUTO || which > K_LATENCY) which = K_AUTO;
     return g_kernel.exchange(which);
 }
 
@@ -450,7 +486,7 @@ int vit_decode_batch_dev_u32(const uint32_t* d_symbols_u32, uint8_t* d_decoded, 
     if (framebits == 0 || nframes == 0) return VIT_OK;
     const size_t nsym = (size_t)nframes * 4u * (framebits + VIT_TAIL);
     const int choice = g_kernel.load();
-    if (u32_in_place(choice, d_symbols_u32, framebits))  // read in place: no scratch, no extra launch
+    if (u32_in_place(choice, d_symbols_u32, framebits, nframes))  // read in place: no scratch, no extra launch
         return launch_decode_u32(choice, d_symbols_u32, nullptr, d_decoded, nullptr, framebits, framebits, nframes,
                                  (int64_t)nsym, (hipStream_t)stream);
     // The narrowed symbols go to this thread's scratch buffer ON THE CALLER'S CURRENT DEVICE (the device its
@@ -527,9 +563,9 @@ static int deconvolve_impl(unsigned int framebits, unsigned int* symbols, unsign
         set_err("deconvolve: bad arguments (framebits=%u)", framebits);
         return 1;
     }
-    if (g_batcher->window_us.load() > 0) {
-        if (hip_device_ready() != VIT_OK) return 1;
-        if (g_batcher->submit(framebits, symbols, decodedBits) != VIT_OK) {
+    InflightGuard inflight(g_batcher->inflight);
+    if (g_batcher->should_batch()) {
+        if (hip_device_ready() != VIT_OK || g_batcher->submit(framebits, symbols, decodedBits) != VIT_OK) {
             g_fault.store(1);
             return 1;
         }
@@ -541,7 +577,7 @@ static int deconvolve_impl(unsigned int framebits, unsigned int* symbols, unsign
     const size_t nsym = 4u * ((size_t)framebits + VIT_TAIL);
     const size_t out_sz = (framebits + 7u) >> 3;
     int rc;
-    if ((rc = grow_pin(nsym * 4 + out_sz + 64)) != VIT_OK || (rc = grow_dev(&t_ctx.d_sym8, &t_ctx.d8_cap, nsym)) != VIT_OK) {
+    if ((rc = grow_pin(nsym * 4 + out_sz + 192)) != VIT_OK || (rc = grow_dev(&t_ctx.d_sym8, &t_ctx.d8_cap, nsym)) != VIT_OK) {
         g_fault.store(1);
         return 1;
     }
@@ -557,12 +593,40 @@ static int deconvolve_impl(unsigned int framebits, unsigned int* symbols, unsign
     // kernel narrows the symbols first.)
     unsigned char* h_out = (unsigned char*)t_ctx.h_pin + nsym * 4;
     memcpy(t_ctx.h_pin, symbols, nsym * 4);
-    if (launch_decode_u32(g_kernel.load(), (const uint32_t*)t_ctx.h_pin_dev, (uint8_t*)t_ctx.d_sym8, (uint8_t*)t_ctx.h_pin_dev + nsym * 4,
+    const int choice = g_kernel.load();
+    hipError_t e;
+    if (pick_kernel(choice, framebits, 1) == K_LATENCY) {
+        // Latency path: the kernel publishes a sequence number in the mapped buffer after its last output byte and
+        // this thread spins on it - the end-of-kernel signal and hipStreamSynchronize's wake-up are off the call's
+        // critical path.  A kernel that does not finish within the spin budget falls back to the stream sync.
+        const size_t flag_off = (nsym * 4 + out_sz + 63u) & ~(size_t)63u;
+        volatile uint32_t* h_flag = reinterpret_cast<volatile uint32_t*>((unsigned char*)t_ctx.h_pin + flag_off);
+        const uint32_t seq = ++t_ctx.seq ? t_ctx.seq : ++t_ctx.seq;  // never 0
+        *h_flag = 0;
+        e = vit_launch_lat(t_ctx.h_pin_dev, true, (uint8_t*)t_ctx.h_pin_dev + nsym * 4, nullptr, framebits, framebits, 1,
+                           t_ctx.stream, reinterpret_cast<uint32_t*>((unsigned char*)t_ctx.h_pin_dev + flag_off), seq);
+        if (e != hipSuccess) return fail("launch", e);
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (__atomic_load_n(const_cast<uint32_t*>(h_flag), __ATOMIC_ACQUIRE) != seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+                if ((e = hipStreamSynchronize(t_ctx.stream)) != hipSuccess) return fail("sync", e);
+                if (__atomic_load_n(const_cast<uint32_t*>(h_flag), __ATOMIC_ACQUIRE) != seq) {
+                    set_err("deconvolve: the kernel ended without publishing its result");
+                    g_fault.store(1);
+                    return 1;
+                }
+            }
+        }
+        memcpy(decodedBits, h_out, out_sz);
+        return 0;
+    }
+    if (launch_decode_u32(choice, (const uint32_t*)t_ctx.h_pin_dev, (uint8_t*)t_ctx.d_sym8, (uint8_t*)t_ctx.h_pin_dev + nsym * 4,
                           nullptr, framebits, framebits, 1, (int64_t)nsym, t_ctx.stream) != VIT_OK) {
         g_fault.store(1);
         return 1;
     }
-    hipError_t e;
     if ((e = hipStreamSynchronize(t_ctx.stream)) != hipSuccess) return fail("sync", e);
     memcpy(decodedBits, h_out, out_sz);
     return 0;
@@ -660,9 +724,24 @@ static int rscheck_impl(unsigned char* p, unsigned int RSDims, unsigned char* ou
     memcpy(h, p, in_sz);
     memcpy(h + in_pad, outVector, out_sz);
     int32_t* h_ret = reinterpret_cast<int32_t*>(h + in_pad + out_pad);
-    *h_ret = -1;
-    hipError_t e = rs_launch(d, d + in_pad, reinterpret_cast<int32_t*>(d + in_pad + out_pad), RSDims, 1, t_ctx.stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(t_ctx.stream);
+    constexpr int32_t PENDING = 0x7FFFFFFF;  // never a return value: those are -1 or a root count
+    const bool poll = RSDims <= 256u;      // the one-workgroup kernel publishes the return value last (see rs_kernel)
+    *h_ret = poll ? PENDING : -1;
+    hipError_t e = rs_launch(d, d + in_pad, reinterpret_cast<int32_t*>(d + in_pad + out_pad), RSDims, 1, t_ctx.stream, poll);
+    if (e == hipSuccess && poll) {
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (__atomic_load_n(h_ret, __ATOMIC_ACQUIRE) == PENDING) {
+            __builtin_ia32_pause();
+            if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+                e = hipStreamSynchronize(t_ctx.stream);
+                if (e == hipSuccess && __atomic_load_n(h_ret, __ATOMIC_ACQUIRE) == PENDING) e = hipErrorUnknown;
+                break;
+            }
+        }
+    } else if (e == hipSuccess) {
+        e = hipStreamSynchronize(t_ctx.stream);
+    }
     if (e != hipSuccess) {
         set_err("RScheckSuperframe: %s", hipGetErrorString(e));
         g_fault.store(1);

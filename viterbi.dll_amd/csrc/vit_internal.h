@@ -21,6 +21,15 @@ bool vit_pk_supported(uint32_t max_framebits);
 hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, const vit_frame_desc* d_desc,
                          uint32_t framebits, uint32_t max_framebits, int64_t nframes,
                          hipStream_t stream);
+// Latency kernel: one frame per wavefront, one path metric per lane, DPP partner fetches (small launches).
+#define VIT_LAT_MAX_FRAMES 2048  // auto selection: up to two waves per SIMD; beyond that the packed kernel's throughput wins
+// done_flag (optional, nframes == 1 only): a word in host-visible memory that receives done_seq, with system-scope
+// release semantics, after the frame's last output byte.
+hipError_t vit_launch_lat(const void* d_symbols, bool sym32, uint8_t* d_out, const vit_frame_desc* d_desc,
+                          uint32_t framebits, uint32_t max_framebits, int64_t nframes,
+                          hipStream_t stream, uint32_t* done_flag = nullptr, uint32_t done_seq = 0);
+// frames the latency kernel can keep resident at one wave per SIMD or so for this frame length (LDS-limited)
+int64_t vit_lat_capacity(uint32_t max_framebits, int dev);
 // Length-sorted (longest first) copy of a device descriptor table; d_bins = 2*VIT_SORT_BINS words of scratch.
 hipError_t vit_sort_descs_launch(const vit_frame_desc* d_desc, vit_frame_desc* d_sorted, int64_t nframes,
                                  uint32_t max_framebits, unsigned* d_bins, hipStream_t stream);
@@ -28,8 +37,10 @@ hipError_t vit_sort_descs_launch(const vit_frame_desc* d_desc, vit_frame_desc* d
 hipError_t vit_launch_pack(const uint32_t* d_sym32, uint8_t* d_sym8, int64_t nsym,
                            hipStream_t stream);
 // RS(120,110) superframe check, one lane per column.
+// host_polls_ret (nsf == 1, rsdims <= 256): d_ret is host-visible and receives its value with system-scope release
+// semantics after the last output byte, so the host may spin on it instead of synchronising the stream.
 hipError_t rs_launch(const uint8_t* d_p, uint8_t* d_out, int32_t* d_ret, uint32_t rsdims,
-                     int64_t nsf, hipStream_t stream);
+                     int64_t nsf, hipStream_t stream, bool host_polls_ret = false);
 
 // ---- host-side helpers shared by the TUs -------------------------------------------------------
 // per-thread error text behind vit_last_error() (printf-style)

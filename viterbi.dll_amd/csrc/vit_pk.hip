@@ -481,7 +481,8 @@ u32 traceback_part(const char* dec, u32* scratch, u32* img, u32 fstride, u32 lan
 template <bool SYM32>
 __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict__ sym, uint8_t* __restrict__ out,
                                                         const vit_frame_desc* __restrict__ desc, u32 framebits_uniform,
-                                                        long long nframes, PkLayout lay, u32 ngroups, unsigned* counter) {
+                                                        long long nframes, PkLayout lay, u32 ngroups, unsigned* counter,
+                                                        u32 vmax) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* dec = lds;                  // [block - R][lane] -> (acc0, acc1); the last block spills into tab
     char* tab = lds + lay.dec_bytes;  // [tau][pair][c] -> M; after the ACS: last block, scratch, image
@@ -564,7 +565,9 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
                 ooff[k] = desc[f].out_offset;
                 // a descriptor the launch was not sized for (longer than max_framebits, or odd) is skipped rather
                 // than allowed to run off the LDS layout; so is one whose symbols are not dword aligned
-                if (fbits[k] > lay.maxfb || (fbits[k] & 1u) || (soff[k] & 3u)) fbits[k] = 0;
+                // (vmax = the launch's max_framebits; it exceeds lay.maxfb when this kernel only takes the short
+                // groups of a length-sorted mixed table, see vit_launch_pk)
+                if (fbits[k] > vmax || (fbits[k] & 1u) || (soff[k] & 3u)) fbits[k] = 0;
             } else {
                 fbits[k] = framebits_uniform;
                 soff[k] = (size_t)f * 4u * (framebits_uniform + VIT_TAIL);
@@ -573,7 +576,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
         }
         maxfb = fbits[k] > maxfb ? fbits[k] : maxfb;
     }
-    if (maxfb == 0) continue;
+    if (maxfb == 0 || maxfb > lay.maxfb) continue;  // nothing valid / a group of the long-frame kernel
     const u32 nb = (maxfb + VIT_TAIL + 15u) >> 4, R = pk_reg_blocks(nb);
     const u32 fstride = pk_img_stride(maxfb);  // image dwords per frame (+ slack for the shifted spill)
     const u32 T_max = maxfb + VIT_TAIL;
@@ -694,7 +697,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
                                                              const vit_frame_desc* __restrict__ desc,
                                                              u32 framebits_uniform, long long nframes, PkLayout lay,
                                                              uint2* spill, u32 spill_blocks, unsigned* counter,
-                                                             u32 ngroups) {
+                                                             u32 ngroups, u32 short_max) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* dec = lds;                  // 16 blocks; the 17th (last) lands on the dead table
     char* tab = lds + lay.dec_bytes;  // [tau][pair][c] -> M; after the ACS: last block, scratch, image
@@ -752,6 +755,9 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
             maxfb = fbits[k] > maxfb ? fbits[k] : maxfb;
         }
         if (maxfb == 0) continue;
+        // length-sorted mixed table: from the first group that fits the single-segment kernel on, the rest is
+        // that kernel's (it keeps two thirds of the history in VGPRs instead of spilling it)
+        if (maxfb <= short_max) break;
         const u32 nblk = (maxfb + VIT_TAIL + 15u) >> 4;
         const u32 G = nblk > LONG_LDS_BLOCKS ? nblk - LONG_LDS_BLOCKS : 0u;  // spilled blocks (<= spill_blocks)
         const u32 T_max = maxfb + VIT_TAIL;
@@ -856,6 +862,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
 }
 
 constexpr u32 PK_MAX_FRAMEBITS = VIT_MAX_FRAMEBITS;
+constexpr u32 PK_SHORT_MAX = SEG_BLOCKS * 16u - VIT_TAIL;  // 778: the longest frame of one segment (49 blocks)
 
 }  // namespace
 
@@ -930,10 +937,10 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
     if (!need_counter && !sort) {
         if (sym32)
             hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
-                               d_desc, framebits, (long long)nframes, lay, (u32)groups, (unsigned*)nullptr);
+                               d_desc, framebits, (long long)nframes, lay, (u32)groups, (unsigned*)nullptr, lay.maxfb);
         else
             hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
-                               d_desc, framebits, (long long)nframes, lay, (u32)groups, (unsigned*)nullptr);
+                               d_desc, framebits, (long long)nframes, lay, (u32)groups, (unsigned*)nullptr, lay.maxfb);
         return hipGetLastError();
     }
     const u32 spill_blocks = is_long ? nblk - LONG_LDS_BLOCKS : 0u;
@@ -964,19 +971,33 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
     unsigned* counter = reinterpret_cast<unsigned*>(base);
     if (need_counter && (e = hipMemsetAsync(base, 0, 256, stream)) != hipSuccess) return e;
     if (is_long) {
+        // A length-sorted table is split between the two kernels: the long-frame kernel stops at the first group
+        // that fits one segment, the single-segment kernel (second launch, same stream) skips the groups before it.
+        const u32 short_max = sort ? PK_SHORT_MAX : 0u;
         uint2* spill = reinterpret_cast<uint2*>(base + SCRATCH_HDR + desc_bytes);
         if (sym32)
             hipLaunchKernelGGL(vit_pk_long_kernel<true>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
-                               d_desc, framebits, (long long)nframes, lay, spill, spill_blocks, counter, (u32)groups);
+                               d_desc, framebits, (long long)nframes, lay, spill, spill_blocks, counter, (u32)groups,
+                               short_max);
         else
             hipLaunchKernelGGL(vit_pk_long_kernel<false>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
-                               d_desc, framebits, (long long)nframes, lay, spill, spill_blocks, counter, (u32)groups);
+                               d_desc, framebits, (long long)nframes, lay, spill, spill_blocks, counter, (u32)groups,
+                               short_max);
+        if (short_max && (e = hipGetLastError()) == hipSuccess) {
+            const PkLayout ls = pk_layout(PK_SHORT_MAX);
+            if (sym32)
+                hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)groups), dim3(64), ls.total, stream, d_sym, d_out,
+                                   d_desc, framebits, (long long)nframes, ls, (u32)groups, (unsigned*)nullptr, max_framebits);
+            else
+                hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)groups), dim3(64), ls.total, stream, d_sym, d_out,
+                                   d_desc, framebits, (long long)nframes, ls, (u32)groups, (unsigned*)nullptr, max_framebits);
+        }
     } else if (sym32) {
         hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
-                           d_desc, framebits, (long long)nframes, lay, (u32)groups, counter);
+                           d_desc, framebits, (long long)nframes, lay, (u32)groups, counter, lay.maxfb);
     } else {
         hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
-                           d_desc, framebits, (long long)nframes, lay, (u32)groups, counter);
+                           d_desc, framebits, (long long)nframes, lay, (u32)groups, counter, lay.maxfb);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     return hipEventRecord(sc.ev, stream);

@@ -471,23 +471,21 @@ u32 traceback_part(const char* dec, u32* scratch, u32* img, u32 fstride, u32 lan
 }
 
 // Single-segment kernel: every frame of the launch fits 49 blocks (framebits <= 778; the FIC fast path).
-#ifndef VIT_STAGGER
-#define VIT_STAGGER 0  /* persistent variants only: start-up delay per wave slot, in cycles per trellis step */
-#endif
-#ifndef VIT_PERSIST
-#define VIT_PERSIST 0  /* 0: one workgroup per group of 4 frames (default: measured fastest, profiles/r02_ab_persist.txt);
-                          1: persistent, static stride; 2: persistent, atomic counter */
-#endif
+// One workgroup (= one wave) per group of 4 frames, dispatched by the hardware.  A persistent form of this kernel
+// (workgroups looping over groups, static stride or atomic counter, with and without a start-up stagger) was
+// measured 7-12 % SLOWER on the benchmark batch and is not kept: profiles/r02_ab_persist.txt, r02_ab_stagger.txt,
+// r02_ab_noprio.txt.  Even the loop scaffolding alone (grid = groups, one trip) cost 12 % through the register
+// allocation it led to (128 VGPRs / 104 SGPRs instead of 113 / 63): profiles/r02_ab_r1kernel_vs_loop.txt.
 template <bool SYM32>
 __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict__ sym, uint8_t* __restrict__ out,
                                                         const vit_frame_desc* __restrict__ desc, u32 framebits_uniform,
-                                                        long long nframes, PkLayout lay, u32 ngroups, unsigned* counter,
-                                                        u32 vmax) {
+                                                        long long nframes, PkLayout lay, u32 vmax) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* dec = lds;                  // [block - R][lane] -> (acc0, acc1); the last block spills into tab
     char* tab = lds + lay.dec_bytes;  // [tau][pair][c] -> M; after the ACS: last block, scratch, image
     u32* img = reinterpret_cast<u32*>(lds + lay.img_off);  // output bit image, 4 frames
     const u32 lane = threadIdx.x;
+    const long long f0 = (long long)blockIdx.x * 4;
 #if VIT_PRIO
     // Stagger the waves that share a SIMD: different issue priorities make them drift apart, so the
     // latency-bound traceback of one overlaps the ACS of the others instead of all four hitting it together.
@@ -503,52 +501,6 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
     }
 #endif
 
-    // ---- lane constants ----
-    const u32 l5 = lane & 31u, pair = lane >> 5;
-    Lanes L;
-#pragma unroll
-    for (int rho = 0; rho < 5; rho++) {
-        const u32 i = ((l5 << rho) | (l5 >> (5 - rho))) & 31u;  // butterfly index rol5(l, rho)
-        const u32 i0 = i & 1u, i1 = (i >> 1) & 1u, i2 = (i >> 2) & 1u, i3 = (i >> 3) & 1u, i4 = (i >> 4) & 1u;
-        const u32 c = (i1 ^ i2 ^ i4) | ((i0 ^ i1 ^ i2) << 1) | ((i0 ^ i3) << 2);  // parity((2i)&poly_j), const.asm:27-63
-        L.toff[rho] = pair * 32u + c * 4u;
-    }
-    Consts C;
-    C.hi = HI;
-    asm volatile("" : "+v"(C.hi));  // keep it in a VGPR
-    const u32 tau = lane >> 1, pp = lane & 1u;  // pre-pass lane = (tau, pair pp)
-    u32 sel[4];
-    {
-        const u32 hb = (tau & 1u) ? 0x0C000C00u : 0x0D000D00u;  // even step: 0xFF high bytes (= +0xFF00)
-#pragma unroll
-        for (int k = 0; k < 4; k++) sel[k] = hb | (0x00040000u + 0x00010001u * k);  // byte k of half 0 / half 1
-    }
-
-    // Workgroups are persistent: as many as fit the chip, each takes group after group of 4 frames
-    // (static stride, or the next one from an atomic counter), so the per-workgroup set-up and the LDS
-    // allocation are paid once and the waves of a SIMD drift apart instead of marching in rounds.
-#if VIT_PERSIST && VIT_STAGGER
-    // Persistent waves that start together stay phase-locked: all four waves of a SIMD reach their (latency-bound)
-    // tracebacks at the same time, round after round.  Delay wave slot s by s quarters of a group's run time
-    // ONCE; while a slot sleeps the others have the SIMD to themselves, so little is lost.
-    {
-        u32 hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        const u32 naps = ((hwid & 3u) * (lay.maxfb + VIT_TAIL) * (u32)VIT_STAGGER) >> 13;  // 8128 cycles per nap
-        for (u32 i = 0; i < naps; i++) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
-#if VIT_PERSIST == 2
-    for (;;) {
-        u32 grp = 0;
-        if (lane == 0) grp = atomicAdd(counter, 1u);
-        grp = (u32)__builtin_amdgcn_readfirstlane((int)grp);
-        if (grp >= ngroups) break;
-#else
-    (void)counter;
-    for (u32 grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-#endif
-    const long long f0 = (long long)grp * 4;
     // ---- per-frame parameters (wave-uniform loads) ----
     u32 fbits[4];
     size_t soff[4], ooff[4];
@@ -564,7 +516,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
                 soff[k] = desc[f].sym_offset;
                 ooff[k] = desc[f].out_offset;
                 // a descriptor the launch was not sized for (longer than max_framebits, or odd) is skipped rather
-                // than allowed to run off the LDS layout; so is one whose symbols are not dword aligned
+                // than allowed to run off the LDS layout; so is one whose symbols are not dword aligned.
                 // (vmax = the launch's max_framebits; it exceeds lay.maxfb when this kernel only takes the short
                 // groups of a length-sorted mixed table, see vit_launch_pk)
                 if (fbits[k] > vmax || (fbits[k] & 1u) || (soff[k] & 3u)) fbits[k] = 0;
@@ -576,17 +528,37 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
         }
         maxfb = fbits[k] > maxfb ? fbits[k] : maxfb;
     }
-    if (maxfb == 0 || maxfb > lay.maxfb) continue;  // nothing valid / a group of the long-frame kernel
+    if (maxfb == 0 || maxfb > lay.maxfb) return;  // nothing valid / a group of the long-frame kernel
     const u32 nb = (maxfb + VIT_TAIL + 15u) >> 4, R = pk_reg_blocks(nb);
     const u32 fstride = pk_img_stride(maxfb);  // image dwords per frame (+ slack for the shifted spill)
     const u32 T_max = maxfb + VIT_TAIL;
 
-    // ---- pre-pass frame pointers: lane = (tau = lane>>1, pair pp = lane&1) ----
+    // ---- ACS lane constants ----
+    const u32 l5 = lane & 31u, pair = lane >> 5;
+    Lanes L;
+#pragma unroll
+    for (int rho = 0; rho < 5; rho++) {
+        const u32 i = ((l5 << rho) | (l5 >> (5 - rho))) & 31u;  // butterfly index rol5(l, rho)
+        const u32 i0 = i & 1u, i1 = (i >> 1) & 1u, i2 = (i >> 2) & 1u, i3 = (i >> 3) & 1u, i4 = (i >> 4) & 1u;
+        const u32 c = (i1 ^ i2 ^ i4) | ((i0 ^ i1 ^ i2) << 1) | ((i0 ^ i3) << 2);  // parity((2i)&poly_j), const.asm:27-63
+        L.toff[rho] = pair * 32u + c * 4u;
+    }
+    Consts C;
+    C.hi = HI;
+    asm volatile("" : "+v"(C.hi));  // keep it in a VGPR
+    // ---- pre-pass lane constants: lane = (tau = lane>>1, pair pp = lane&1) ----
+    const u32 tau = lane >> 1, pp = lane & 1u;
     const u32 a_fb = pp ? fbits[2] : fbits[0], b_fb = pp ? fbits[3] : fbits[1];
     const u32 a_T = a_fb ? a_fb + VIT_TAIL : 0u, b_T = b_fb ? b_fb + VIT_TAIL : 0u;
     constexpr size_t SB = SYM32 ? 4 : 1;  // bytes per soft symbol in memory
     const uint8_t* a_sym = sym + SB * (pp ? soff[2] : soff[0]);
     const uint8_t* b_sym = sym + SB * (pp ? soff[3] : soff[1]);
+    u32 sel[4];
+    {
+        const u32 hb = (tau & 1u) ? 0x0C000C00u : 0x0D000D00u;  // even step: 0xFF high bytes (= +0xFF00)
+#pragma unroll
+        for (int k = 0; k < 4; k++) sel[k] = hb | (0x00040000u + 0x00010001u * k);  // byte k of half 0 / half 1
+    }
     u32 A = l5 == 0 ? 0u : 0x003F003Fu, B = 0x003F003Fu;  // const.asm:19-25 (0-based, step 0 is even)
     u32 acc0 = 0, acc1 = 0;
     v32u r0, r1;  // register-resident decisions of blocks [0,R)
@@ -663,8 +635,6 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
             }
         }
     }
-    __syncthreads();  // the image is read before the next group's pre-pass reuses the region
-    }  // persistent loop
 }
 
 // ---- frames longer than one segment: decisions beyond the last 17 blocks go through HBM ---------
@@ -922,25 +892,21 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
 #endif
     const bool sort = d_desc != nullptr && nframes >= SORT_MIN_FRAMES && sort_enabled();
     const PkLayout lay = is_long ? pk_layout_long(max_framebits) : pk_layout(max_framebits);
-    // persistent workgroups: as many as fit the chip
     long long grid = groups;
-#if VIT_PERSIST == 0
-    if (is_long)
-#endif
-    {
+    if (is_long) {  // the long-frame kernel is persistent: as many workgroups as fit the chip
         u32 per_cu = (160u * 1024u) / lay.total;
         if (per_cu > 16u) per_cu = 16u;  // 4 waves per SIMD (launch bounds)
         grid = (long long)per_cu * vit_device_cus(dev);
         if (grid > groups) grid = groups;
     }
-    const bool need_counter = is_long || VIT_PERSIST == 2;
+    const bool need_counter = is_long;
     if (!need_counter && !sort) {
         if (sym32)
             hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
-                               d_desc, framebits, (long long)nframes, lay, (u32)groups, (unsigned*)nullptr, lay.maxfb);
+                               d_desc, framebits, (long long)nframes, lay, lay.maxfb);
         else
             hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
-                               d_desc, framebits, (long long)nframes, lay, (u32)groups, (unsigned*)nullptr, lay.maxfb);
+                               d_desc, framebits, (long long)nframes, lay, lay.maxfb);
         return hipGetLastError();
     }
     const u32 spill_blocks = is_long ? nblk - LONG_LDS_BLOCKS : 0u;
@@ -987,17 +953,17 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
             const PkLayout ls = pk_layout(PK_SHORT_MAX);
             if (sym32)
                 hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)groups), dim3(64), ls.total, stream, d_sym, d_out,
-                                   d_desc, framebits, (long long)nframes, ls, (u32)groups, (unsigned*)nullptr, max_framebits);
+                                   d_desc, framebits, (long long)nframes, ls, max_framebits);
             else
                 hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)groups), dim3(64), ls.total, stream, d_sym, d_out,
-                                   d_desc, framebits, (long long)nframes, ls, (u32)groups, (unsigned*)nullptr, max_framebits);
+                                   d_desc, framebits, (long long)nframes, ls, max_framebits);
         }
     } else if (sym32) {
         hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
-                           d_desc, framebits, (long long)nframes, lay, (u32)groups, counter, lay.maxfb);
+                           d_desc, framebits, (long long)nframes, lay, lay.maxfb);
     } else {
         hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
-                           d_desc, framebits, (long long)nframes, lay, (u32)groups, counter, lay.maxfb);
+                           d_desc, framebits, (long long)nframes, lay, lay.maxfb);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     return hipEventRecord(sc.ev, stream);

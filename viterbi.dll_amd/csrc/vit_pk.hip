@@ -342,37 +342,43 @@ __host__ __device__ inline PkLayout pk_layout(u32 maxfb) {  // single-segment ke
 //     n' = bit j of l,   l' = l with bit j replaced by the decision k read at step t
 // (this is ChainBack's E = (E>>1)|(k<<7), deconvolve.cpp:424-433, seen through the rotating
 // lane<->state map).  The history words hold NOT k, so the code tracks the complement
-// P = (31-l)<<3 | (1-n)<<2: inserting the stored bit unchanged, and 252 - P is the byte
-// offset of the word to read.  State 0 is P = 252.
+// P = (31-l)<<3 | (1-n)<<2 - the stored bit is inserted unchanged - and the decision blocks are laid
+// out in LDS in those same complemented coordinates (dec_slot() below), so that P IS the byte offset
+// of the history word inside its block.  State 0 is P = 252.
 constexpr u32 P_ZERO = 252u;
 constexpr u32 TB_WARM = 30u;  // warm-up steps (multiple of 5) a speculative block starts above its own range
 
+// LDS byte offset, inside a 512-byte decision block, of the (acc1, acc0) pair of ACS lane `lane`:
+// [pair][31 - l][1 - n] - the register with n = 1 first.  Every store of a block uses it.
+DEV u32 dec_slot(u32 lane) { return (lane >> 5) * 256u + (31u - (lane & 31u)) * 8u; }
+
 // One step back for every active lane.  JJ = 3 + j is the position of lane bit j inside P.
-//   word  = dec[(t>>4) - slot0][pair][l][n]            (base folds pair, slot0 and the 252)
-//   kb    = bit (t & 15) + 16*half of it               (= NOT decision)
-//   P     = P with bit JJ := kb, bit 2 := old bit JJ
+//   x     = (t - 16*slot0) << 5: bits 9.. select the block, bits 5..8 are t & 15
+//   PC    = P | pair << 8 | half << 1: with the mirrored block layout the 16 history bits of (frame, l, n)
+//           for block t >> 4 are the halfword at (x & ~511) | PC
+//   kb    = bit t & 15 of it (= NOT decision);   P: bit JJ := kb, bit 2 := old bit JJ
 template <int JJ>
-DEV void tb_step(u32& P, u32& kb, u32 t, const char* base, u32 halfshift) {
-    const u32 w = *reinterpret_cast<const u32*>(base + ((t << 5) & ~511u) - P);
-    kb = (w >> ((t & 15u) | halfshift)) & 1u;
-    const u32 b = (P >> JJ) & 1u;
-    P = (P & ~((1u << JJ) | 4u)) | (kb << JJ) | (b << 2);
+DEV void tb_step(u32& PC, u32& kb, u32 x) {
+    // x already carries the LDS address of dec (a multiple of 512, checked in traceback_part): no add left here
+    const u32 w = *reinterpret_cast<const __attribute__((address_space(3))) unsigned short*>((x & ~511u) | PC);
+    kb = __builtin_amdgcn_ubfe(w, (x >> 5) & 15u, 1u);
+    const u32 t = ((PC >> (JJ - 2)) & 4u) | (kb << JJ);
+    PC = bfi((1u << JJ) | 4u, t, PC);
 }
 
 // Runs block-relative indices i = i_from .. i_to (downwards; i_from + 1 and i_to are multiples of 5
 // so that the phase of every unrolled position is static: j(i) = (j0 - i) mod 5, JA = j(i_from)).
 // Lanes take part while `on` and i <= i_start.  RECORD: collect kb bits of index i into words
-// (bit i&31 of word i>>5), flushed to scratch when a word is complete.
+// (bit i&31 of word i>>5), flushed to scratch when a word is complete.  xbase = x of index 0.
 template <bool RECORD, int JA>
-DEV void tb_loop(u32& P, u32* scratch, int i_from, int i_to, bool on, u32 i_start, u32 tbase, const char* base,
-                 u32 halfshift) {
+DEV void tb_loop(u32& PC, u32* scratch, int i_from, int i_to, bool on, u32 i_start, u32 xbase) {
     u32 cur = 0;
     for (int i = i_from; i >= i_to; i -= 5) {
 #define TB_ONE(K)                                                                  \
     {                                                                              \
         const int ii = i - (K);                                                    \
         u32 kb = 0;                                                                \
-        if (on && (u32)ii <= i_start) tb_step<3 + (JA + (K)) % 5>(P, kb, tbase + (u32)ii, base, halfshift); \
+        if (on && (u32)ii <= i_start) tb_step<3 + (JA + (K)) % 5>(PC, kb, xbase + ((u32)ii << 5)); \
         if (RECORD) {                                                              \
             cur |= kb << (ii & 31);                                                \
             if ((ii & 31) == 0) {                                                  \
@@ -386,15 +392,14 @@ DEV void tb_loop(u32& P, u32* scratch, int i_from, int i_to, bool on, u32 i_star
     }
 }
 template <bool RECORD>
-DEV void tb_run(u32& P, u32* scratch, int i_from, int i_to, bool on, u32 i_start, u32 tbase, const char* base,
-                u32 halfshift, u32 j0) {
+DEV void tb_run(u32& PC, u32* scratch, int i_from, int i_to, bool on, u32 i_start, u32 xbase, u32 j0) {
     // i_from % 5 == 4  ->  j(i_from) = (j0 - 4) mod 5 = (j0 + 1) % 5
     switch ((j0 + 1u) % 5u) {
-        case 0: tb_loop<RECORD, 0>(P, scratch, i_from, i_to, on, i_start, tbase, base, halfshift); break;
-        case 1: tb_loop<RECORD, 1>(P, scratch, i_from, i_to, on, i_start, tbase, base, halfshift); break;
-        case 2: tb_loop<RECORD, 2>(P, scratch, i_from, i_to, on, i_start, tbase, base, halfshift); break;
-        case 3: tb_loop<RECORD, 3>(P, scratch, i_from, i_to, on, i_start, tbase, base, halfshift); break;
-        default: tb_loop<RECORD, 4>(P, scratch, i_from, i_to, on, i_start, tbase, base, halfshift); break;
+        case 0: tb_loop<RECORD, 0>(PC, scratch, i_from, i_to, on, i_start, xbase); break;
+        case 1: tb_loop<RECORD, 1>(PC, scratch, i_from, i_to, on, i_start, xbase); break;
+        case 2: tb_loop<RECORD, 2>(PC, scratch, i_from, i_to, on, i_start, xbase); break;
+        case 3: tb_loop<RECORD, 3>(PC, scratch, i_from, i_to, on, i_start, xbase); break;
+        default: tb_loop<RECORD, 4>(PC, scratch, i_from, i_to, on, i_start, xbase); break;
     }
 }
 
@@ -429,25 +434,30 @@ u32 traceback_part(const char* dec, u32* scratch, u32* img, u32 fstride, u32 lan
     const u32 i_warm = BL - 1u + TB_WARM;
     const u32 i_start = i_last < i_warm ? i_last : i_warm;
     const bool fixed = has_work && i_last <= i_warm;  // starts from the true position: never re-traced
-    // LDS byte address of the word for (t, P): base + ((t>>4)<<9) - P ; base folds pair, slot0 and the 252
-    const char* base = dec + (fi >> 1) * 256u + P_ZERO - (slot0 << 9);
-    const u32 halfshift = (fi & 1u) * 16u;
+    // PC = P | C: the lane's constant address bits (pair, half) ride along in the tracked position
+    const u32 C = (fi >> 1) * 256u + (fi & 1u) * 2u;
+    // x of block-relative index 0 (every t traced is >= 16*slot0), with the LDS address of `dec` folded in: the
+    // block select is (x & ~511), so that address must be a multiple of 512 (it is 0: dynamic LDS, no static LDS)
+    const u32 dbase = (u32)(uintptr_t)(const __attribute__((address_space(3))) char*)dec;
+    if (dbase & 511u) __builtin_trap();
+    const u32 xbase = ((tbase - slot0 * 16u) << 5) + dbase;
     const u32 j0 = (4u + 5u - ((ts + 5u - 1u) % 5u)) % 5u;  // j of block-relative index 0: 4 - ((ts-1) mod 5)
+    const u32 PC_top = P_top | C;
 
-    u32 P = fixed ? P_top : P_ZERO, P_out = P_top;
+    u32 P = fixed ? PC_top : (P_ZERO | C), P_out = PC_top;
     // pass 0: warm-up (no bits kept) then the block itself
-    tb_run<false>(P, scratch, (int)i_warm, (int)BL, has_work, i_start, tbase, base, halfshift, j0);
+    tb_run<false>(P, scratch, (int)i_warm, (int)BL, has_work, i_start, xbase, j0);
     u32 P_in = P;  // position the trace passed through at the block's top (meaningless for short top blocks)
-    tb_run<true>(P, scratch, (int)BL - 1, 0, has_work, i_start, tbase, base, halfshift, j0);
+    tb_run<true>(P, scratch, (int)BL - 1, 0, has_work, i_start, xbase, j0);
     if (has_work) P_out = P;
     for (int pass = 0; pass < 17; pass++) {
-        const u32 nxt = __shfl_down(P_out, 1);
-        const u32 new_in = (q < q_top) ? nxt : P_top;
+        const u32 nxt = __shfl_down(P_out, 1);  // the block above belongs to the same frame: same C
+        const u32 new_in = (q < q_top) ? nxt : PC_top;
         const bool changed = has_work && !fixed && new_in != P_in;
         if (!__any(changed)) break;
         if (changed) P_in = new_in;
         P = new_in;
-        tb_run<true>(P, scratch, (int)BL - 1, 0, changed, BL - 1u, tbase, base, halfshift, j0);
+        tb_run<true>(P, scratch, (int)BL - 1, 0, changed, BL - 1u, xbase, j0);
         if (changed) P_out = P;
     }
     // decoded bit index of step t is t - 6 (chainback skips the 6 tail decisions); decoded bit = NOT stored bit
@@ -467,7 +477,7 @@ u32 traceback_part(const char* dec, u32* scratch, u32* img, u32 fstride, u32 lan
             }
         }
     }
-    return __shfl(P_out, (int)(fi * 16u));  // block 0 of the frame ends at step ts
+    return __shfl(P_out, (int)(fi * 16u)) & 0xFCu;  // block 0 of the frame ends at step ts; C stripped
 }
 
 // Single-segment kernel: every frame of the launch fits 49 blocks (framebits <= 778; the FIC fast path).
@@ -535,6 +545,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
 
     // ---- ACS lane constants ----
     const u32 l5 = lane & 31u, pair = lane >> 5;
+    const u32 dslot = dec_slot(lane);  // where this lane's history words go inside a decision block
     Lanes L;
 #pragma unroll
     for (int rho = 0; rho < 5; rho++) {
@@ -585,7 +596,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
                 r1[rb] = acc1;
             } else {
                 if (rb + 1u == nb) __syncthreads();  // the last block lands on the table: all reads done first
-                *reinterpret_cast<uint2*>(dec + (rb - R) * DEC_BLOCK + lane * 8) = make_uint2(acc0, acc1);
+                *reinterpret_cast<uint2*>(dec + (rb - R) * DEC_BLOCK + dslot) = make_uint2(acc1, acc0);
             }
             v = v == 4 ? 0 : v + 1;
         }
@@ -609,7 +620,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
 #pragma unroll
         for (u32 b = 0; b < VREG_BLOCKS; b++)
             if (b >= g0 && b < g1)
-                *reinterpret_cast<uint2*>(dec + (b - g0) * DEC_BLOCK + lane * 8) = make_uint2(r0[b], r1[b]);
+                *reinterpret_cast<uint2*>(dec + (b - g0) * DEC_BLOCK + dslot) = make_uint2(r1[b], r0[b]);
         __syncthreads();
         const u32 tsg = g0 ? g0 * 16u : VIT_TAIL, tend = g1 * 16u;
         const u32 te = t_T < tend ? t_T : tend, te_max = T_max < tend ? T_max : tend;
@@ -677,6 +688,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
 
     // ---- lane constants (same roles as in vit_pk_kernel) ----
     const u32 l5 = lane & 31u, pair = lane >> 5;
+    const u32 dslot = dec_slot(lane);  // where this lane's history words go inside a decision block
     Lanes L;
 #pragma unroll
     for (int rho = 0; rho < 5; rho++) {
@@ -760,7 +772,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
                     wspill[(size_t)rb * 64u] = make_uint2(acc0, acc1);
                 } else {
                     if (rb + 1u == nblk) __syncthreads();  // the last block lands on the table: all reads done first
-                    *reinterpret_cast<uint2*>(dec + (rb - G) * DEC_BLOCK + lane * 8) = make_uint2(acc0, acc1);
+                    *reinterpret_cast<uint2*>(dec + (rb - G) * DEC_BLOCK + dslot) = make_uint2(acc1, acc0);
                 }
                 v = v == 4 ? 0 : v + 1;
             }
@@ -817,7 +829,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
             __syncthreads();
 #pragma unroll
             for (u32 k = 0; k < DUMP_GROUP; k++)
-                *reinterpret_cast<uint2*>(dec + k * DEC_BLOCK + lane * 8) = d[k];
+                *reinterpret_cast<uint2*>(dec + k * DEC_BLOCK + dslot) = make_uint2(d[k].y, d[k].x);
             __syncthreads();
             if (g0) fetch(g0 > DUMP_GROUP ? g0 - DUMP_GROUP : 0u, g0);  // next group down, in flight during this part
             const u32 tsg = g0 ? g0 * 16u : VIT_TAIL, tend = g1 * 16u;

@@ -24,18 +24,22 @@ static inline unsigned par8(unsigned x) {
     return x & 1u;
 }
 
+/* branch masks (parity((2i) & poly_j), const.asm:27-63 in natural order): built once per process, not per frame */
+static uint8_t g_mk[4][32] __attribute__((aligned(32)));
+__attribute__((constructor)) static void vo_avx2_init_masks(void) {
+    static const int polys[4] = {109, 79, 83, 109};
+    for (int j = 0; j < 4; j++)
+        for (int i = 0; i < 32; i++) g_mk[j][i] = par8((2u * i) & polys[j]) ? 0xFF : 0;
+}
+
 __attribute__((target("avx2")))
 int vo_deconvolve_avx2_u8(unsigned framebits, const uint8_t *sym,
                           unsigned char *out) {
     if (framebits > 9216) return 1;
-    static const int polys[4] = {109, 79, 83, 109};
-    uint8_t mk[4][32];
-    for (int j = 0; j < 4; j++)
-        for (int i = 0; i < 32; i++) mk[j][i] = par8((2u * i) & polys[j]) ? 0xFF : 0;
-    const __m256i k0 = _mm256_loadu_si256((const __m256i *)mk[0]);
-    const __m256i k1 = _mm256_loadu_si256((const __m256i *)mk[1]);
-    const __m256i k2 = _mm256_loadu_si256((const __m256i *)mk[2]);
-    const __m256i k3 = _mm256_loadu_si256((const __m256i *)mk[3]);
+    const __m256i k0 = _mm256_load_si256((const __m256i *)g_mk[0]);
+    const __m256i k1 = _mm256_load_si256((const __m256i *)g_mk[1]);
+    const __m256i k2 = _mm256_load_si256((const __m256i *)g_mk[2]);
+    const __m256i k3 = _mm256_load_si256((const __m256i *)g_mk[3]);
     const __m256i c63 = _mm256_set1_epi8(63);
 
     uint64_t dec[9216 + 6]; /* on the stack like the reference (deconvolve.cpp:127) */

@@ -35,6 +35,7 @@ for r in rows[:6]:
 
 tot = {}
 meta = {}
+pmc_json = None
 for p in ("p1", "p2", "p3", "p4"):
     fn = os.path.join(src, "pmc_%s.csv" % p)
     if not os.path.exists(fn):
@@ -58,11 +59,11 @@ if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
     traffic = fetch + write
     lines.append("\nHBM traffic per launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 = %.4g + %.4g = %.4g B; algorithmic %.4g B; ratio %.3f\n"
                  % (fetch, write, traffic, alg, traffic / alg))
-    with open(os.path.join(dst, "pmc_traffic.json"), "w") as f:
-        json.dump({"round": tag, "kernel": KERNEL, "hbm_bytes_per_launch": int(traffic), "fetch_bytes_corrected": int(fetch),
-                   "write_bytes": int(write), "algorithmic_bytes_per_launch": alg,
-                   "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units; "
-                             "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a streaming read)"}, f, indent=1)
+    pmc_json = {"round": tag, "kernel": KERNEL, "source": "tools/collect_profiles.sh %s: rocprofv3 --pmc passes of `python bench.py --no-cpu`" % tag,
+                "hbm_bytes_per_launch": int(traffic), "fetch_bytes_corrected": int(fetch),
+                "write_bytes": int(write), "algorithmic_bytes_per_launch": alg,
+                "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units; "
+                          "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a streaming read)"}
 if avg_ns:
     lines.append("kernel avg (rocprof) %.1f us vs bench HIP-event kernel_ms %.4f ms\n" % (avg_ns / 1e3, bench["roofline"]["kernel_ms"]))
 if "SQ_ACTIVE_INST_VALU" in tot and "GRBM_GUI_ACTIVE" in tot:
@@ -71,13 +72,27 @@ if "SQ_ACTIVE_INST_VALU" in tot and "GRBM_GUI_ACTIVE" in tot:
     valu_busy = tot["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * kernel_cycles)
     lines.append("kernel cycles %.4g (clock %.2f GHz); VALU busy = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * cycles) = %.1f %%\n"
                  % (kernel_cycles, kernel_cycles / (avg_ns or 1) , 100.0 * valu_busy))
+    if pmc_json is not None:
+        pmc_json["valu_busy"] = round(valu_busy, 4)
 if "SQ_LDS_BANK_CONFLICT" in tot and "SQ_LDS_IDX_ACTIVE" in tot and tot["SQ_LDS_IDX_ACTIVE"]:
     lines.append("LDS: bank-conflict cycles / index-active cycles = %.1f %%; LDS-instruction busy = SQ_ACTIVE_INST_LDS*4 / (256 CUs * cycles) = %.1f %%\n" % (
         100.0 * tot["SQ_LDS_BANK_CONFLICT"] / tot["SQ_LDS_IDX_ACTIVE"],
         100.0 * tot.get("SQ_ACTIVE_INST_LDS", 0) * 4.0 / (256.0 * (tot.get("GRBM_GUI_ACTIVE", 0) / 8.0 or 1))))
 if "SQ_WAVES" in tot:
     w = tot["SQ_WAVES"]
+    if pmc_json is not None and "SQ_INSTS_VALU" in tot:
+        steps = bench["config"]["framebits"] + 6
+        pmc_json["valu_insts_per_wave"] = round(tot["SQ_INSTS_VALU"] / w, 1)
+        pmc_json["valu_insts_per_frame_step"] = round(tot["SQ_INSTS_VALU"] / w / steps / 4.0, 3)  # 4 frames per wave
     lines.append("per wave: VALU %.0f  SALU %.0f  LDS %.0f  wave-cycles(quad) %.0f\n" % (
         tot.get("SQ_INSTS_VALU", 0) / w, tot.get("SQ_INSTS_SALU", 0) / w, tot.get("SQ_INSTS_LDS", 0) / w, tot.get("SQ_WAVE_CYCLES", 0) / w))
+if pmc_json is not None:
+    with open(os.path.join(dst, "pmc_traffic.json"), "w") as f:
+        json.dump(pmc_json, f, indent=1)
+lines.append("\n# note on the dispatch columns of rocprofv3's counter CSV: VGPR_Count 60 = (granulated_workitem_vgpr_count + 1) * 4,\n"
+             "# i.e. the kernel descriptor's 15 granules priced at the pre-gfx90a granule of 4; gfx950 allocates in granules of 8, so\n"
+             "# the wave holds 15 * 8 = 120 registers for the code object's .vgpr_count 114 (512 / 120 -> 4 waves per SIMD).\n"
+             "# LDS_Block_Size 0 is the STATIC group segment (.group_segment_fixed_size 0); the 10240 B per workgroup are DYNAMIC LDS\n"
+             "# passed at launch (hipLaunchKernelGGL's sharedMemBytes), and they are what limits residency to 16 waves per CU.\n")
 open(os.path.join(dst, "%s_rocprof_summary.txt" % tag), "w").writelines(lines)
 print("".join(lines))

@@ -88,7 +88,7 @@ struct Lanes {
 // v_cndmask_b32 through VCC for ~22.  So for J < 4 the partner values travel through the LDS
 // crossbar (ds_swizzle: no VALU slot, no LDS memory) and two v_cndmask_b32_e64 pick them up.
 #ifndef VIT_SWZ_ALL
-#define VIT_SWZ_ALL 0
+#define VIT_SWZ_ALL 1  /* lane bits 3 and 2 through ds_swizzle too: 1.3 % faster than masked DPP moves since the round-2 traceback (profiles/r02_ab_k3_swz.txt) */
 #endif
 #ifndef VIT_X01_DPP
 #define VIT_X01_DPP 0

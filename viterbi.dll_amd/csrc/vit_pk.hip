@@ -88,7 +88,9 @@ struct Lanes {
 // v_cndmask_b32 through VCC for ~22.  So for J < 4 the partner values travel through the LDS
 // crossbar (ds_swizzle: no VALU slot, no LDS memory) and two v_cndmask_b32_e64 pick them up.
 #ifndef VIT_SWZ_ALL
-#define VIT_SWZ_ALL 1  /* lane bits 3 and 2 through ds_swizzle too: 1.3 % faster than masked DPP moves since the round-2 traceback (profiles/r02_ab_k3_swz.txt) */
+#define VIT_SWZ_ALL 1  /* which of lane bits 3 (bit 0 of this mask) and 2 (bit 1) are exchanged through ds_swizzle instead of
+                          masked DPP moves.  Since the round-2 traceback the kernel sits between the VALU and the LDS limit:
+                          none 0.467 ms, bit 3 only 0.458, bit 2 only 0.459, both 0.462 (profiles/r02_ab_k3_swz.txt) */
 #endif
 #ifndef VIT_X01_DPP
 #define VIT_X01_DPP 0
@@ -109,11 +111,11 @@ DEV void exchange(u32& A, u32& B, u32 N0, u32 N1, u32 lane) {
         auto r = __builtin_amdgcn_permlane16_swap(N0, N1, false, false);
         A = r[0];
         B = r[1];
-    } else if constexpr (J == 3 && !VIT_SWZ_ALL) {
+    } else if constexpr (J == 3 && !(VIT_SWZ_ALL & 1)) {
         // masked DPP moves stay in the VALU (10 cycles incl. one copy) and keep LDS latency off this step
         A = __builtin_amdgcn_update_dpp(N0, N1, 0x128 /*row_ror:8*/, 0xF, 0xC, false);
         B = __builtin_amdgcn_update_dpp(N1, N0, 0x128, 0xF, 0x3, false);
-    } else if constexpr (J == 2 && !VIT_SWZ_ALL) {
+    } else if constexpr (J == 2 && !(VIT_SWZ_ALL & 2)) {
         A = __builtin_amdgcn_update_dpp(N0, N1, 0x114 /*row_shr:4*/, 0xF, 0xA, false);
         B = __builtin_amdgcn_update_dpp(N1, N0, 0x104 /*row_shl:4*/, 0xF, 0x5, false);
     } else {

@@ -10,7 +10,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "configs_" + tag)
 dst = os.path.join(root, "profiles")
-OURS = ("vit_pk", "vit_wave", "vit_pack", "rs_kernel", "desc_")
+OURS = ("vit_pk", "vit_lat", "vit_wave", "vit_pack", "rs_kernel", "desc_")
 
 with open(os.path.join(dst, "%s_other_configs.jsonl" % tag), "w") as f:
     for name in ("configs.jsonl", "rs.jsonl", "hostpaths.jsonl"):
@@ -18,6 +18,9 @@ with open(os.path.join(dst, "%s_other_configs.jsonl" % tag), "w") as f:
             if line.startswith("{"):
                 f.write(line)
 shutil.copy(os.path.join(src, "vitbench.txt"), os.path.join(dst, "%s_vitbench.txt" % tag))
+if os.path.exists(os.path.join(src, "small_batch.jsonl")):
+    with open(os.path.join(dst, "%s_small_batch.jsonl" % tag), "w") as f:
+        f.writelines(l for l in open(os.path.join(src, "small_batch.jsonl")) if l.startswith("{"))
 with open(os.path.join(dst, "%s_soak.txt" % tag), "w") as f:
     f.write("# tests/tools/soak.py on MI355X: GPU (auto kernel) vs CPU oracle, bit-exact compare of every output byte\n"
             "# decode (5 seed sets): lengths 768/288/1536/3072/6912/9216/776/784/770/9214 x {Eb/N0 3 dB, 0 dB, 12 dB, uniform random bytes, saturation/renormalisation stress patterns};\n"

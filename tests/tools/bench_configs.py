@@ -84,6 +84,31 @@ for label, sym in (("noisy Eb/N0 3 dB", sym_noisy), ("random bytes", sym_rand)):
                       "Mbit_s": round(float(fbs.sum()) / ms / 1e3, 1), "parity_sample_ok": ok}), flush=True)
 del sym_noisy, sym_rand
 
+# ---- a mostly-short table: 64512 FIC frames + 1024 frames of 3072 bits (< 1/8 long: the sorted table is split, the
+# FIC frames run in the single-segment kernel without spilling their history) ----
+fbs2 = np.array([768] * 64512 + [3072] * 1024)
+rng.shuffle(fbs2)
+desc2, sb2, ob2 = V.make_descs(fbs2.tolist())
+so2 = torch.from_numpy(desc2["sym_offset"].astype(np.int64)).to(dev)
+sym2 = torch.empty(sb2, dtype=torch.uint8, device=dev)
+for fb in (768, 3072):
+    idx = torch.from_numpy(np.nonzero(fbs2 == fb)[0]).to(dev)
+    fr = make_frames(int(idx.numel()), fb, seed=400 + fb, device=dev)
+    pos = so2[idx][:, None] + torch.arange(fr.shape[1], device=dev)[None, :]
+    sym2[pos.reshape(-1)] = fr.reshape(-1)
+    del fr, pos
+out2 = torch.zeros(ob2, dtype=torch.uint8, device=dev)
+d_desc2 = torch.from_numpy(desc2.view(np.uint8)).to(dev)
+ms = timeit(lambda: V.decode_varlen_dev(sym2, out2, d_desc2, len(fbs2), 3072), steps=10, warm=2, prewarm_ms=100.0)
+sh, oh = sym2.cpu().numpy(), out2.cpu().numpy()
+ok = True
+for i in rng.choice(len(fbs2), 64, replace=False):
+    fb = int(fbs2[i]); so = int(desc2["sym_offset"][i]); oo = int(desc2["out_offset"][i])
+    ok &= bool(np.array_equal(O.decode_batch(fb, sh[so:so + O.sym_len(fb)])[0], oh[oo:oo + fb // 8]))
+print(json.dumps({"case": "mixed table, 64512 FIC + 1024 x 3072-bit frames (split between the kernels)", "frames": len(fbs2),
+                  "ms": round(ms, 3), "Mbit_s": round(float(fbs2.sum()) / ms / 1e3, 1), "parity_sample_ok": ok}), flush=True)
+del sym2, out2
+
 # ---- config 5: RS(120,110) superframes ----
 for rsdims in (24, 12, 4):
     nsf = 16384

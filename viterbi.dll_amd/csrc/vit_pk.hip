@@ -72,6 +72,7 @@ DEV u32 avg4(u32 a, u32 b) { return __builtin_amdgcn_lerp(a, b, 0x01010101u); } 
 constexpr int TAB_BYTES = 2048;  // 32 steps x 2 pairs x 8 triples x M (4 B); 63-M is one v_sub in the ACS
 constexpr int DEC_BLOCK = 512;   // 16 steps of decisions: 64 lanes x 8 B
 constexpr u32 HI = 0xFF00FF00u;  // +0xFF00 in both halves
+constexpr unsigned PK_SPLIT_DEN = 8;  // a sorted table is split between the kernels when < 1/8 of its frames are long
 
 struct Lanes {
     u32 toff[5];  // LDS byte offset of this lane's (M,MM) entry for phase rho
@@ -491,7 +492,11 @@ u32 traceback_part(const char* dec, u32* scratch, u32* img, u32 fstride, u32 lan
 template <bool SYM32>
 __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict__ sym, uint8_t* __restrict__ out,
                                                         const vit_frame_desc* __restrict__ desc, u32 framebits_uniform,
-                                                        long long nframes, PkLayout lay, u32 vmax) {
+                                                        long long nframes, PkLayout lay, u32 vmax,
+                                                        const unsigned* __restrict__ split_gate) {
+    // second launch behind the long-frame kernel on a length-sorted table: runs only if that kernel left the short
+    // groups to it (same test there, see vit_launch_pk)
+    if (split_gate && (unsigned long long)*split_gate * PK_SPLIT_DEN >= (unsigned long long)nframes) return;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* dec = lds;                  // [block - R][lane] -> (acc0, acc1); the last block spills into tab
     char* tab = lds + lay.dec_bytes;  // [tau][pair][c] -> M; after the ACS: last block, scratch, image
@@ -680,13 +685,17 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
                                                              const vit_frame_desc* __restrict__ desc,
                                                              u32 framebits_uniform, long long nframes, PkLayout lay,
                                                              uint2* spill, u32 spill_blocks, unsigned* counter,
-                                                             u32 ngroups, u32 short_max) {
+                                                             u32 ngroups, u32 short_max,
+                                                             const unsigned* __restrict__ split_gate) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* dec = lds;                  // 16 blocks; the 17th (last) lands on the dead table
     char* tab = lds + lay.dec_bytes;  // [tau][pair][c] -> M; after the ACS: last block, scratch, image
     u32* img = reinterpret_cast<u32*>(lds + lay.img_off);
     const u32 lane = threadIdx.x;
     uint2* wspill = spill + (size_t)blockIdx.x * spill_blocks * 64u + lane;
+    // few long frames in the table: leave the short groups to the single-segment kernel (no spill for them);
+    // many: keep them - they are the small jobs that level the end of this kernel's longest-first schedule
+    const bool split = split_gate && (unsigned long long)*split_gate * PK_SPLIT_DEN < (unsigned long long)nframes;
 
     // ---- lane constants (same roles as in vit_pk_kernel) ----
     const u32 l5 = lane & 31u, pair = lane >> 5;
@@ -741,7 +750,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
         if (maxfb == 0) continue;
         // length-sorted mixed table: from the first group that fits the single-segment kernel on, the rest is
         // that kernel's (it keeps two thirds of the history in VGPRs instead of spilling it)
-        if (maxfb <= short_max) break;
+        if (maxfb <= short_max && split) break;
         const u32 nblk = (maxfb + VIT_TAIL + 15u) >> 4;
         const u32 G = nblk > LONG_LDS_BLOCKS ? nblk - LONG_LDS_BLOCKS : 0u;  // spilled blocks (<= spill_blocks)
         const u32 T_max = maxfb + VIT_TAIL;
@@ -917,10 +926,10 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
     if (!need_counter && !sort) {
         if (sym32)
             hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
-                               d_desc, framebits, (long long)nframes, lay, lay.maxfb);
+                               d_desc, framebits, (long long)nframes, lay, lay.maxfb, (const unsigned*)nullptr);
         else
             hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
-                               d_desc, framebits, (long long)nframes, lay, lay.maxfb);
+                               d_desc, framebits, (long long)nframes, lay, lay.maxfb, (const unsigned*)nullptr);
         return hipGetLastError();
     }
     const u32 spill_blocks = is_long ? nblk - LONG_LDS_BLOCKS : 0u;
@@ -953,31 +962,35 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
     if (is_long) {
         // A length-sorted table is split between the two kernels: the long-frame kernel stops at the first group
         // that fits one segment, the single-segment kernel (second launch, same stream) skips the groups before it.
+        // That pays only when few frames are long (measured: config 3, 91 % long frames, lost 12 % to the split - the
+        // short groups are what levels the tail of the longest-first schedule), so both kernels test the same
+        // device-side count: after the sort, bin cursor [98] = number of frames of >= 777 bits.
         const u32 short_max = sort ? PK_SHORT_MAX : 0u;
+        const unsigned* gate = sort ? reinterpret_cast<const unsigned*>(base + 256) + VIT_SORT_BINS + ((PK_SHORT_MAX + 7u) >> 3) : nullptr;
         uint2* spill = reinterpret_cast<uint2*>(base + SCRATCH_HDR + desc_bytes);
         if (sym32)
             hipLaunchKernelGGL(vit_pk_long_kernel<true>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
                                d_desc, framebits, (long long)nframes, lay, spill, spill_blocks, counter, (u32)groups,
-                               short_max);
+                               short_max, gate);
         else
             hipLaunchKernelGGL(vit_pk_long_kernel<false>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
                                d_desc, framebits, (long long)nframes, lay, spill, spill_blocks, counter, (u32)groups,
-                               short_max);
+                               short_max, gate);
         if (short_max && (e = hipGetLastError()) == hipSuccess) {
             const PkLayout ls = pk_layout(PK_SHORT_MAX);
             if (sym32)
                 hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)groups), dim3(64), ls.total, stream, d_sym, d_out,
-                                   d_desc, framebits, (long long)nframes, ls, max_framebits);
+                                   d_desc, framebits, (long long)nframes, ls, max_framebits, gate);
             else
                 hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)groups), dim3(64), ls.total, stream, d_sym, d_out,
-                                   d_desc, framebits, (long long)nframes, ls, max_framebits);
+                                   d_desc, framebits, (long long)nframes, ls, max_framebits, gate);
         }
     } else if (sym32) {
         hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
-                           d_desc, framebits, (long long)nframes, lay, lay.maxfb);
+                           d_desc, framebits, (long long)nframes, lay, lay.maxfb, (const unsigned*)nullptr);
     } else {
         hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
-                           d_desc, framebits, (long long)nframes, lay, lay.maxfb);
+                           d_desc, framebits, (long long)nframes, lay, lay.maxfb, (const unsigned*)nullptr);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     return hipEventRecord(sc.ev, stream);

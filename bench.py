@@ -201,12 +201,22 @@ def main(argv=None):
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.stub:
-            dist.init_process_group(args.backend)
-        else:
-            os.environ.setdefault("VITERBI_AMD_DEVICE", str(local_rank))
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(args.backend, device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner to stdout when its first communicator comes up: keep stdout for the JSON line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.stub:
+                dist.init_process_group(args.backend)
+            else:
+                os.environ.setdefault("VITERBI_AMD_DEVICE", str(local_rank))
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group(args.backend, device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     elif not args.stub:
         torch.cuda.set_device(0)
     dev = torch.device("cpu") if args.stub else torch.device("cuda", local_rank if spawned else 0)
@@ -273,25 +283,24 @@ def main(argv=None):
     if dist:
         dist.barrier()
     sync()
-    if args.stub:
-        evs = []
-    else:
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # HIP events on the launch stream bracket the whole timed region (one pair, not one per step: an event between
+    # two launches costs the GPU a few microseconds of idle time per step)
+    ev0 = ev1 = None
+    if not args.stub:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    if evs:
-        for a, b in evs:
-            a.record()
-            step()
-            b.record()
-    else:
-        for _ in range(args.steps):
-            step()
+    if ev0 is not None:
+        ev0.record()
+    for _ in range(args.steps):
+        step()
+    if ev1 is not None:
+        ev1.record()
     sync()
     if dist:
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs])) if evs else dt / max(1, args.steps) * 1e3
+    kern_ms = ev0.elapsed_time(ev1) / max(1, args.steps) if ev0 is not None else dt / max(1, args.steps) * 1e3
     if dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -343,9 +352,10 @@ def main(argv=None):
             result["roofline"]["note"] = "kernel_ms here spans scatter+decode+gather; see shard mode for the kernel"
         if world == 1 and not args.no_cpu and not args.stub:
             O = _vitpkg.load_oracle()  # checker + timed CPU baseline only
-            sym_host = d_sym.cpu().numpy()
+            in_shard_mode = args.mode == "shard" or not dist
+            sym_host = (d_sym if in_shard_mode else d_all).cpu().numpy()
             base, ref = cpu_baseline(O, sym_host, FRAMEBITS)
-            got = d_out.cpu().numpy()
+            got = (d_out if in_shard_mode else d_all_out).cpu().numpy()
             bad = int((got != ref).any(axis=1).sum())
             result["cpu_baseline"] = base
             result["parity"] = {"frames_checked": n, "frames_differing": bad, "bit_exact": bad == 0}
@@ -378,8 +388,16 @@ def main_multi(args):
     def step():
         V.decode_stream_multi(d_all, d_all_out, FRAMEBITS, n_total, devices, args.chunk_frames, rootf, flags)
 
-    for _ in range(max(1, args.warmup)):
-        step()
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)  # RCCL prints a version banner to stdout when its first communicator comes up
+    os.dup2(2, 1)
+    try:
+        for _ in range(max(1, args.warmup)):
+            step()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()  # synchronous

@@ -106,7 +106,7 @@ typedef struct vit_frame_desc {
 int vit_decode_batch_dev(const uint8_t *d_symbols_u8, uint8_t *d_decoded,
                          uint32_t framebits, int64_t nframes, void *stream);
 /* Same, symbols still in the reference ABI format (u32 per symbol, low byte
- * used).  With a 16-byte aligned buffer and framebits % 8 == 0 the decoder
+ * used).  With a 16-byte aligned buffer the decoder
  * reads them in place (narrowing fused into the kernel); otherwise they are
  * narrowed on the device into an internal scratch buffer first. */
 int vit_decode_batch_dev_u32(const uint32_t *d_symbols_u32, uint8_t *d_decoded,

@@ -8,6 +8,8 @@
 // Reference boundary being replaced: viterbi.def:4-8, deconvolve.cpp:551-554,
 // rschecksf.cpp:65-93, dllmain.cpp:156-160, setupdll.cpp:195-270 (dispatcher),
 // exc_handler.cpp:150-249 (fault -> save mode).
+#include <sched.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -610,7 +612,8 @@ static int deconvolve_impl(unsigned int framebits, unsigned int* symbols, unsign
         unsigned spins = 0;
         while (__atomic_load_n(const_cast<uint32_t*>(h_flag), __ATOMIC_ACQUIRE) != seq) {
             __builtin_ia32_pause();
-            if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+            if (++spins > 4096u && (spins & 63u) == 0) sched_yield();  // more callers than cores: let the others run
+            if ((spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
                 if ((e = hipStreamSynchronize(t_ctx.stream)) != hipSuccess) return fail("sync", e);
                 if (__atomic_load_n(const_cast<uint32_t*>(h_flag), __ATOMIC_ACQUIRE) != seq) {
                     set_err("deconvolve: the kernel ended without publishing its result");
@@ -733,7 +736,8 @@ static int rscheck_impl(unsigned char* p, unsigned int RSDims, unsigned char* ou
         unsigned spins = 0;
         while (__atomic_load_n(h_ret, __ATOMIC_ACQUIRE) == PENDING) {
             __builtin_ia32_pause();
-            if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+            if (++spins > 4096u && (spins & 63u) == 0) sched_yield();
+            if ((spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
                 e = hipStreamSynchronize(t_ctx.stream);
                 if (e == hipSuccess && __atomic_load_n(h_ret, __ATOMIC_ACQUIRE) == PENDING) e = hipErrorUnknown;
                 break;

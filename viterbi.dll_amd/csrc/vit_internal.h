@@ -14,7 +14,7 @@ hipError_t vit_launch_wave(const uint8_t* d_sym, uint8_t* d_out, const vit_frame
                            uint32_t framebits, uint32_t max_framebits, int64_t nframes,
                            hipStream_t stream);
 // Packed kernel: 4 frames per wavefront, 2 states x 2 frames per lane register.
-// Needs framebits % 8 == 0 and 4 frames' decisions to fit the LDS budget.
+// Every even framebits <= 9216 (frames longer than 778 bits spill their history through HBM).
 bool vit_pk_supported(uint32_t max_framebits);
 // sym32: d_symbols holds the reference ABI's u32-per-symbol format (16-byte aligned; sym_offset
 // then counts symbols); the narrowing to the low byte is fused into the kernel's pre-pass.

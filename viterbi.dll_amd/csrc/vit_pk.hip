@@ -874,7 +874,19 @@ struct ScratchCtx {
     size_t cap = 0;
     hipEvent_t ev = nullptr;
     int dev = -1;
+    // a split table runs its two kernels side by side: the long-frame kernel goes to `side`, forked from and joined
+    // back into the caller's stream with these events
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    void drop_side() {
+        if (side) (void)hipStreamDestroy(side);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        side = nullptr;
+        ev_fork = ev_join = nullptr;
+    }
     ~ScratchCtx() {
+        drop_side();
         if (buf) (void)hipFree(buf);
         if (ev) (void)hipEventDestroy(ev);
     }
@@ -942,6 +954,7 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
         sc.cap = 0;
         if (sc.ev) (void)hipEventDestroy(sc.ev);
         sc.ev = nullptr;
+        if (sc.dev != dev) sc.drop_side();  // streams and events belong to a device
         if ((e = hipMalloc(&sc.buf, need + need / 4)) != hipSuccess) return e;
         sc.cap = need + need / 4;
         sc.dev = dev;
@@ -968,22 +981,39 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
         const u32 short_max = sort ? PK_SHORT_MAX : 0u;
         const unsigned* gate = sort ? reinterpret_cast<const unsigned*>(base + 256) + VIT_SORT_BINS + ((PK_SHORT_MAX + 7u) >> 3) : nullptr;
         uint2* spill = reinterpret_cast<uint2*>(base + SCRATCH_HDR + desc_bytes);
+        // With a split in prospect the long-frame kernel runs on a side stream, forked behind the sort: a handful of
+        // long groups cannot fill the chip, the single-segment kernel's workgroups take the rest of it meanwhile.
+        hipStream_t ls = stream;
+        if (short_max) {
+            if (!sc.side) {
+                if ((e = hipStreamCreateWithFlags(&sc.side, hipStreamNonBlocking)) != hipSuccess) return e;
+                if ((e = hipEventCreateWithFlags(&sc.ev_fork, hipEventDisableTiming)) != hipSuccess) return e;
+                if ((e = hipEventCreateWithFlags(&sc.ev_join, hipEventDisableTiming)) != hipSuccess) return e;
+            }
+            if ((e = hipEventRecord(sc.ev_fork, stream)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(sc.side, sc.ev_fork, 0)) != hipSuccess) return e;
+            ls = sc.side;
+        }
         if (sym32)
-            hipLaunchKernelGGL(vit_pk_long_kernel<true>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
+            hipLaunchKernelGGL(vit_pk_long_kernel<true>, dim3((unsigned)grid), dim3(64), lay.total, ls, d_sym, d_out,
                                d_desc, framebits, (long long)nframes, lay, spill, spill_blocks, counter, (u32)groups,
                                short_max, gate);
         else
-            hipLaunchKernelGGL(vit_pk_long_kernel<false>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
+            hipLaunchKernelGGL(vit_pk_long_kernel<false>, dim3((unsigned)grid), dim3(64), lay.total, ls, d_sym, d_out,
                                d_desc, framebits, (long long)nframes, lay, spill, spill_blocks, counter, (u32)groups,
                                short_max, gate);
         if (short_max && (e = hipGetLastError()) == hipSuccess) {
-            const PkLayout ls = pk_layout(PK_SHORT_MAX);
+            const PkLayout lsh = pk_layout(PK_SHORT_MAX);
             if (sym32)
-                hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)groups), dim3(64), ls.total, stream, d_sym, d_out,
-                                   d_desc, framebits, (long long)nframes, ls, max_framebits, gate);
+                hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)groups), dim3(64), lsh.total, stream, d_sym, d_out,
+                                   d_desc, framebits, (long long)nframes, lsh, max_framebits, gate);
             else
-                hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)groups), dim3(64), ls.total, stream, d_sym, d_out,
-                                   d_desc, framebits, (long long)nframes, ls, max_framebits, gate);
+                hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)groups), dim3(64), lsh.total, stream, d_sym, d_out,
+                                   d_desc, framebits, (long long)nframes, lsh, max_framebits, gate);
+            // join: whatever the caller enqueues next waits for both kernels
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            if ((e = hipEventRecord(sc.ev_join, sc.side)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(stream, sc.ev_join, 0)) != hipSuccess) return e;
         }
     } else if (sym32) {
         hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,

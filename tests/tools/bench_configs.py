@@ -109,30 +109,35 @@ print(json.dumps({"case": "mixed table, 64512 FIC + 1024 x 3072-bit frames (spli
                   "ms": round(ms, 3), "Mbit_s": round(float(fbs2.sum()) / ms / 1e3, 1), "parity_sample_ok": ok}), flush=True)
 del sym2, out2
 
-# ---- config 5: RS(120,110) superframes ----
+# ---- config 5: RS(120,110) superframes, 16384 per launch ----
+# "light" = what the decoder leaves behind at Eb/N0 = 3 dB (one symbol error in 6 % of the columns: the pipeline below
+# corrects 24.6 k symbols in 393 k columns); "stress" = errors in 5/9 of the columns incl. uncorrectable ones (1/9):
+# nearly every superframe fails - the worst case for the correction path, not an operating point.
 for rsdims in (24, 12, 4):
-    nsf = 16384
-    rng = np.random.default_rng(rsdims)
-    base_n = 64
-    p = np.empty((base_n, 120, rsdims), np.uint8)
-    for s in range(base_n):
-        for j in range(rsdims):
-            cw = O.rs_encode(rng.integers(0, 256, 110, dtype=np.uint8))
-            ne = int(rng.choice([0, 0, 0, 0, 1, 2, 3, 5, 6]))
-            pos = rng.choice(120, ne, replace=False)
-            cw[pos] ^= rng.integers(1, 256, ne, dtype=np.uint8)
-            p[s, :, j] = cw
-    p = p.reshape(base_n, -1)
-    ret_ref, out_ref = O.rs_check_batch(p, rsdims)
-    d_p = torch.from_numpy(p).to(dev).repeat(nsf // base_n, 1).contiguous()
-    d_out = torch.zeros((nsf, 110 * rsdims), dtype=torch.uint8, device=dev)
-    d_ret = torch.zeros(nsf, dtype=torch.int32, device=dev)
-    ms = timeit(lambda: V.rs_batch_dev(d_p, d_out, d_ret, rsdims, nsf))
-    ok = bool(np.array_equal(d_ret[:base_n].cpu().numpy(), ret_ref)) and \
-        bool(np.array_equal(d_out[:base_n].cpu().numpy(), out_ref))
-    print(json.dumps({"case": "config5 RS", "rsdims": rsdims, "superframes": nsf, "ms": round(ms, 4),
-                      "GB_s_in_plus_out": round(nsf * 230 * rsdims / ms / 1e6, 1),
-                      "superframes_per_s": round(nsf / ms * 1e3), "parity_ok": ok}), flush=True)
+    for mode in ("light", "stress"):
+        nsf = 16384
+        rng = np.random.default_rng(rsdims)
+        base_n = 64
+        p = np.empty((base_n, 120, rsdims), np.uint8)
+        for s in range(base_n):
+            for j in range(rsdims):
+                cw = O.rs_encode(rng.integers(0, 256, 110, dtype=np.uint8))
+                ne = int(rng.random() < 0.06) if mode == "light" else int(rng.choice([0, 0, 0, 0, 1, 2, 3, 5, 6]))
+                pos = rng.choice(120, ne, replace=False)
+                cw[pos] ^= rng.integers(1, 256, ne, dtype=np.uint8)
+                p[s, :, j] = cw
+        p = p.reshape(base_n, -1)
+        ret_ref, out_ref = O.rs_check_batch(p, rsdims)
+        d_p = torch.from_numpy(p).to(dev).repeat(nsf // base_n, 1).contiguous()
+        d_out = torch.zeros((nsf, 110 * rsdims), dtype=torch.uint8, device=dev)
+        d_ret = torch.zeros(nsf, dtype=torch.int32, device=dev)
+        ms = timeit(lambda: V.rs_batch_dev(d_p, d_out, d_ret, rsdims, nsf))
+        ok = bool(np.array_equal(d_ret[:base_n].cpu().numpy(), ret_ref)) and \
+            bool(np.array_equal(d_out[:base_n].cpu().numpy(), out_ref))
+        print(json.dumps({"case": "config5 RS", "errors": mode, "rsdims": rsdims, "superframes": nsf, "ms": round(ms, 4),
+                          "GB_s_in_plus_out": round(nsf * 230 * rsdims / ms / 1e6, 1),
+                          "superframes_per_s": round(nsf / ms * 1e3), "failed_superframes_in_sample": int((ret_ref < 0).sum()),
+                          "parity_ok": ok}), flush=True)
 
 # ---- config 5, whole pipeline: 16384 superframes x (5 x deconvolve -> RScheckSuperframe), RSDims = 24 ----
 # payload = valid RS(120,110) codewords column-wise (own encoder), mother code, AWGN at Eb/N0 = 3 dB;

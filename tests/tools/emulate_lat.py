@@ -52,7 +52,9 @@ def decode(sym, fb):
         pm = np.minimum(p + 63 - M, 255)
         n = np.minimum(om, pm)
         lj = (LANES >> j) & 1
-        dec[t] = np.where(lj == 1, om <= pm, pm <= om)
+        hi = np.where(lj == 1, om, pm)       # the candidate that came from predecessor i+32
+        dec[t] = n == hi                     # tie -> 1 on both sides (deconvolve.cpp:352-374)
+        assert np.array_equal(dec[t].astype(bool), np.where(lj == 1, om <= pm, pm <= om))
         if t & 1 and n[0] > 150:
             n = np.maximum(n - 63, 0)
         m = n

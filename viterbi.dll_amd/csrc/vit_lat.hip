@@ -14,9 +14,9 @@
 // * n = min(own + M, partner + (63-M)) as u16 with `v_add_u16 clamp` on m + 0xFF00 (= paddusb), same
 //   0-based / biased alternation as vit_pk.hip; renormalisation (state 0 > 150 -> psubusb 63, every second
 //   step) is v_readfirstlane + two scalar instructions + one v_sub_u16 clamp.
-// * Decision bit (tie -> 1, deconvolve.cpp:352-374): two v_cmp into SGPR masks, combined on the scalar unit
-//   (the roles of "own" and "partner" swap with lane bit j), shifted into a per-lane history word by ONE
-//   v_addc_co_u32 (acc = 2*acc + carry-in); one ds_write per 32 steps.
+// * Decision bit (tie -> 1, deconvolve.cpp:352-374) = [survivor == the candidate that came from state i+32]: one
+//   select by a constant lane mask (the roles of "own" and "partner" swap with lane bit j) and one v_cmp_eq,
+//   shifted into a per-lane history word by ONE v_addc_co_u32 (acc = 2*acc + carry-in); one ds_write per 32 steps.
 // * Branch metrics: the frame's symbols are staged in LDS once (bulk load, one memory latency - it may be
 //   PCIe: deconvolve() hands the kernel mapped host memory); every 64 steps a lane-per-step pre-pass
 //   writes the 8 class metrics (M, 63-M) of those steps.
@@ -96,35 +96,34 @@ DEV u32 add_sat16(u32 a, u32 b) { return __builtin_elementwise_add_sat((u16)a, (
 DEV u32 sub_sat16(u32 a, u32 k) { return __builtin_elementwise_sub_sat((u16)a, (u16)k); }
 DEV u32 min16(u32 a, u32 b) { return __builtin_elementwise_min((u16)a, (u16)b); }
 
-// Decision bits of a step from its two compare masks.  Lanes with bit J clear hold predecessor i: decision =
-// [partner cand <= own cand] (m1 <= m0, tie -> 1); lanes with bit J set hold predecessor i+32: decision =
-// [own cand <= partner cand] (m3 <= m2, tie -> 1) = NOT [partner < own].   d = le ^ ((le ^ ~lt) & lj): 3 SALU.
-template <int J>
-DEV void push_decisions(u32& acc, u64 le, u64 lt) {
-    constexpr u64 LJ[6] = {0xAAAAAAAAAAAAAAAAull, 0xCCCCCCCCCCCCCCCCull, 0xF0F0F0F0F0F0F0F0ull,
-                           0xFF00FF00FF00FF00ull, 0xFFFF0000FFFF0000ull, 0xFFFFFFFF00000000ull};
-    const u64 d = le ^ (~(le ^ lt) & LJ[J]);
+// Decision bit of a step.  Lanes with bit J clear hold predecessor i: decision = [partner cand <= own cand]
+// (m1 <= m0, tie -> 1); lanes with bit J set hold predecessor i+32: decision = [own cand <= partner cand] (m3 <= m2,
+// tie -> 1).  Both are "the survivor equals the candidate that came from i+32": decision = [n == hi], where hi is the
+// partner's candidate for the first kind of lane and the own candidate for the second - one select by a constant
+// lane mask and ONE compare, no scalar instruction (the first version combined two compare masks with four).
+// `after` is not used by the instruction: it only pins it behind the value's definition in the schedule.
+DEV void push_decisions(u32& acc, u64 d, u32 after = 0) {
     u64 cout;
-    asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(acc), "=s"(cout) : "s"(d));  // acc = 2*acc + decision
+    asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(acc), "=s"(cout) : "s"(d), "v"(after));  // acc = 2*acc + decision
 }
 
 // One trellis step.  RHO = t mod 6 (static): partner bit J = (5 - RHO) mod 6, parity of t = parity of RHO.
-// The wave issues in order, so the scalar combine of a step's compare masks and the v_addc that consumes it would
-// stall the next step's metric chain behind two VALU<->SALU hand-offs: the masks (ple, plt) of step t are
-// therefore consumed one step LATER, between the adds and the compares of step t+1 (PENDING = there is one).
+// The wave issues in order, so the v_addc that consumes a step's decision mask would stall the next step's metric
+// chain behind a VALU -> SGPR -> VALU hand-off: the mask (pd) of step t is therefore consumed one step LATER,
+// between the adds and the compare of step t+1 (PENDING = there is one).
 template <int RHO, bool PENDING>
-DEV void step(u32& m, u32& acc, u64& ple, u64& plt, const char* tabrow, u32 toff, u32 lane) {
+DEV void step(u32& m, u32& acc, u64& pd, const char* tabrow, u32 toff, u32 lane) {
     constexpr int J = (5 - RHO + 6) % 6;
     const uint2 X = *reinterpret_cast<const uint2*>(tabrow + toff);  // x: M, y: 63-M (both + 0xFF00 on even steps)
-    const u32 p = partner<J>(m, lane);
     u32 om = add_sat16(m, X.x);
     asm("" : "+v"(om));  // keeps the SLP vectoriser from fusing the two adds into perm + v_pk_add_u16 + SDWA ops
+    const u32 p = partner<J>(m, lane);  // after the own add: m is dead here, the in-place lane swaps need one copy only
     u32 pm = add_sat16(p, X.y);
     asm("" : "+v"(pm));
-    if constexpr (PENDING) push_decisions<(J + 1) % 6>(acc, ple, plt);  // the previous step's partner bit
-    ple = __builtin_amdgcn_ballot_w64((u16)pm <= (u16)om);
-    plt = __builtin_amdgcn_ballot_w64((u16)pm < (u16)om);
+    if constexpr (PENDING) push_decisions(acc, pd, pm);  // not before this step's adds have been issued
     const u32 n = min16(om, pm);
+    const u32 hi = ((lane >> J) & 1u) ? om : pm;  // v_cndmask with a constant lane mask
+    pd = __builtin_amdgcn_ballot_w64((u16)n == (u16)hi);
     if constexpr (RHO & 1) {
         // Renormalize256 (deconvolve.cpp:407-412): state 0 = lane 0; n = m + 0xFF00 here
         // (compare in every lane, take lane 0's bit: one hop shorter than v_readfirstlane + scalar compare)
@@ -144,16 +143,16 @@ DEV void step(u32& m, u32& acc, u64& ple, u64& plt, const char* tabrow, u32 toff
 // dependent chain), history word stored once the decisions of every 32nd step are in.
 template <int S>
 struct ChunkSteps {
-    static DEV void run(u32& m, u32& acc, u64& ple, u64& plt, const char* tab, const u32 (&toff)[6], u32 lane, u32* decw) {
-        step<S % 6, (S > 0)>(m, acc, ple, plt, tab + S * 64, toff[S % 6], lane);
+    static DEV void run(u32& m, u32& acc, u64& pd, const char* tab, const u32 (&toff)[6], u32 lane, u32* decw) {
+        step<S % 6, (S > 0)>(m, acc, pd, tab + S * 64, toff[S % 6], lane);
         if constexpr (S > 0 && S % 32 == 0) decw[(S / 32 - 1) * 64] = acc;  // steps S-32 .. S-1; step t at bit 31 - (t & 31)
-        ChunkSteps<S + 1>::run(m, acc, ple, plt, tab, toff, lane, decw);
+        ChunkSteps<S + 1>::run(m, acc, pd, tab, toff, lane, decw);
     }
 };
 template <>
 struct ChunkSteps<(int)CHUNK> {
-    static DEV void run(u32&, u32& acc, u64& ple, u64& plt, const char*, const u32 (&)[6], u32, u32* decw) {
-        push_decisions<(5 - (int)(CHUNK - 1u) % 6 + 6) % 6>(acc, ple, plt);  // the chunk's last step
+    static DEV void run(u32&, u32& acc, u64& pd, const char*, const u32 (&)[6], u32, u32* decw) {
+        push_decisions(acc, pd);  // the chunk's last step
         decw[(CHUNK / 32u - 1u) * 64u] = acc;
     }
 };
@@ -264,8 +263,8 @@ __global__ __launch_bounds__(64) void vit_lat_kernel(const uint8_t* __restrict__
             prepass_row(ch * CHUNK, lane);
             if (lane < CHUNK - 64u) prepass_row(ch * CHUNK, 64u + lane);
             __syncthreads();
-            u64 ple = 0, plt = 0;
-            ChunkSteps<0>::run(m, acc, ple, plt, tab, toff, lane, dec + ch * (CHUNK / 32u) * 64u + lane);
+            u64 pd = 0;
+            ChunkSteps<0>::run(m, acc, pd, tab, toff, lane, dec + ch * (CHUNK / 32u) * 64u + lane);
         }
         __syncthreads();
 

@@ -125,8 +125,19 @@ __device__ int rs_correct(uint32_t (&s)[NROOTS], uint8_t* col, uint32_t stride, 
     lam[0] = 1;
     b[0] = 0;
     int el = 0;
+    // Single-symbol shortcut.  One error e at position p gives S_i = e * alpha^(i*p): a geometric sequence, and then
+    // Berlekamp-Massey's answer is the unique connection polynomial 1 + (S_1/S_0) x (2L <= 10).  What the Viterbi decoder
+    // leaves behind is almost always that (a burst of a few bits lands in one or two different columns), so when EVERY
+    // erroneous column of the wave passes the test the ten BM iterations are skipped; anything else takes them.
+    bool geo = s[0] != NN && s[1] != NN;
+    const uint32_t lr = mod255(s[1] + NN - s[0]);  // log(S_1 / S_0); meaningless unless geo
+#pragma unroll
+    for (int i = 2; i < NROOTS; i++) geo = geo && s[i] == mod255(s[0] + (uint32_t)i * lr);  // a zero S_i (255) never matches
+    const bool shortcut = __all(geo);
+    if (shortcut) lam[1] = ato[lr];
 #pragma unroll
     for (int r = 1; r <= NROOTS; r++) {  // Berlekamp-Massey (rschecksf.cpp:240-284)
+        if (shortcut) break;
         uint32_t discr = 0;
 #pragma unroll
         for (int i = 0; i < r; i++) {

@@ -105,31 +105,43 @@ struct Lanes {
 #ifndef VIT_PRIO
 #define VIT_PRIO 1  /* measured: ~1 % on the 65536-frame batch */
 #endif
-template <int J>
+#ifndef VIT_PAIR_LSB
+#define VIT_PAIR_LSB 0  /* 1: the pair index is lane bit 0 and the five state bits are lane bits 1..5 (two swap instructions) */
+#endif
+// ACS lane roles: which lane bits carry the butterfly index (l5) and which one the pair.
+DEV u32 acs_l5(u32 lane) { return VIT_PAIR_LSB ? lane >> 1 : lane & 31u; }
+DEV u32 acs_pair(u32 lane) { return VIT_PAIR_LSB ? lane & 1u : lane >> 5; }
+template <int J>  // J = state lane bit (bit J of l5)
 DEV void exchange(u32& A, u32& B, u32 N0, u32 N1, u32 lane) {
-    if constexpr (J == 4) {
+    constexpr int P = J + VIT_PAIR_LSB;  // physical lane bit
+    if constexpr (P == 5) {
+        // swap N0's upper 32 lanes with N1's lower 32 lanes
+        auto r = __builtin_amdgcn_permlane32_swap(N0, N1, false, false);
+        A = r[0];
+        B = r[1];
+    } else if constexpr (P == 4) {
         // swap N0's odd rows with N1's even rows (rows = 16 lanes)
         auto r = __builtin_amdgcn_permlane16_swap(N0, N1, false, false);
         A = r[0];
         B = r[1];
-    } else if constexpr (J == 3 && !(VIT_SWZ_ALL & 1)) {
+    } else if constexpr (P == 3 && !(VIT_SWZ_ALL & 1)) {
         // masked DPP moves stay in the VALU (10 cycles incl. one copy) and keep LDS latency off this step
         A = __builtin_amdgcn_update_dpp(N0, N1, 0x128 /*row_ror:8*/, 0xF, 0xC, false);
         B = __builtin_amdgcn_update_dpp(N1, N0, 0x128, 0xF, 0x3, false);
-    } else if constexpr (J == 2 && !(VIT_SWZ_ALL & 2)) {
+    } else if constexpr (P == 2 && !(VIT_SWZ_ALL & 2)) {
         A = __builtin_amdgcn_update_dpp(N0, N1, 0x114 /*row_shr:4*/, 0xF, 0xA, false);
         B = __builtin_amdgcn_update_dpp(N1, N0, 0x104 /*row_shl:4*/, 0xF, 0x5, false);
     } else {
         // lane bits 0/1 cannot be masked by DPP bank masks (and DPP needs the source lane active)
-        const bool hi = (lane >> J) & 1u;
+        const bool hi = (lane >> P) & 1u;
 #if VIT_X01_DPP
         // all-lane DPP moves + selects: 16 VALU cycles, but no LDS round trip in the dependency chain
-        constexpr int qp = J == 1 ? 0x4E /*quad_perm:[2,3,0,1]*/ : 0xB1 /*quad_perm:[1,0,3,2]*/;
+        constexpr int qp = P == 1 ? 0x4E /*quad_perm:[2,3,0,1]*/ : 0xB1 /*quad_perm:[1,0,3,2]*/;
         const u32 p1 = __builtin_amdgcn_update_dpp(0u, N1, qp, 0xF, 0xF, true);
         const u32 p0 = __builtin_amdgcn_update_dpp(0u, N0, qp, 0xF, 0xF, true);
 #else
         // partner values through ds_swizzle (LDS crossbar, no VALU slot): 8 VALU cycles for the selects
-        constexpr int pat = 0x1F | ((1 << J) << 10);  // BitMode: src lane = lane ^ 2^J within 32
+        constexpr int pat = 0x1F | ((1 << P) << 10);  // BitMode: src lane = lane ^ 2^P within 32
         const u32 p1 = (u32)__builtin_amdgcn_ds_swizzle((int)N1, pat);
         const u32 p0 = (u32)__builtin_amdgcn_ds_swizzle((int)N0, pat);
 #endif
@@ -177,7 +189,11 @@ DEV void acs_step(u32& A, u32& B, u32& acc0, u32& acc1, u32 mt, u32 lane, const 
         // The subtrahend is per frame, i.e. the same for every lane and both registers of a pair, so it
         // commutes with the lane exchange: the broadcast and the exchange are issued together and
         // the subtraction lands on the exchanged registers (one LDS latency instead of two in a row).
+#if VIT_PAIR_LSB
+        const u32 z = (u32)__builtin_amdgcn_ds_bpermute((int)((lane & 1u) << 2), (int)W(n0));  // state 0 of the pair: lane 0 / 1
+#else
         const u32 z = (u32)__builtin_amdgcn_ds_swizzle((int)W(n0), 0);  // lane 0 of each 32-lane group
+#endif
         exchange<4 - RHO>(A, B, W(n0), W(n1), lane);
 #if VIT_K3
         // three instructions: v_pk_add_u16 (bit 15 of each half := m >= 151), v_pk_ashrrev_i16 15, v_and_or_b32
@@ -353,7 +369,7 @@ constexpr u32 TB_WARM = 30u;  // warm-up steps (multiple of 5) a speculative blo
 
 // LDS byte offset, inside a 512-byte decision block, of the (acc1, acc0) pair of ACS lane `lane`:
 // [pair][31 - l][1 - n] - the register with n = 1 first.  Every store of a block uses it.
-DEV u32 dec_slot(u32 lane) { return (lane >> 5) * 256u + (31u - (lane & 31u)) * 8u; }
+DEV u32 dec_slot(u32 lane) { return acs_pair(lane) * 256u + (31u - acs_l5(lane)) * 8u; }
 
 // One step back for every active lane.  JJ = 3 + j is the position of lane bit j inside P.
 //   x     = (t - 16*slot0) << 5: bits 9.. select the block, bits 5..8 are t & 15
@@ -551,7 +567,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
     const u32 T_max = maxfb + VIT_TAIL;
 
     // ---- ACS lane constants ----
-    const u32 l5 = lane & 31u, pair = lane >> 5;
+    const u32 l5 = acs_l5(lane), pair = acs_pair(lane);
     const u32 dslot = dec_slot(lane);  // where this lane's history words go inside a decision block
     Lanes L;
 #pragma unroll
@@ -698,7 +714,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
     const bool split = split_gate && (unsigned long long)*split_gate * PK_SPLIT_DEN < (unsigned long long)nframes;
 
     // ---- lane constants (same roles as in vit_pk_kernel) ----
-    const u32 l5 = lane & 31u, pair = lane >> 5;
+    const u32 l5 = acs_l5(lane), pair = acs_pair(lane);
     const u32 dslot = dec_slot(lane);  // where this lane's history words go inside a decision block
     Lanes L;
 #pragma unroll

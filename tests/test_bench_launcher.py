@@ -46,3 +46,17 @@ def test_under_an_external_launcher_it_is_a_rank():
     r = _run(["--gpus", "1"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
                                "MASTER_PORT": "29731"})
     assert r["n_gpus"] == 1 and r["config"]["launch"] == "external launcher"
+
+
+def test_under_torch_distributed_run_with_two_ranks():
+    """the driver's N > 1 command line: python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29779", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--stub", "--frames", "32"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["launch"] == "external launcher"

@@ -11,9 +11,9 @@
 //   only, and both survivors (2i, 2i+1) stay in those same two lanes: a step moves NO metric, it only
 //   fetches the partner lane's value (lane ^ 2^j): DPP for j <= 3, v_permlane{16,32}_swap + select for
 //   j = 4, 5.  State 0 is always lane 0.
-// * n = min(own + M, partner + (63-M)) as u16 with `v_add_u16 clamp` on m + 0xFF00 (= paddusb), same
-//   0-based / biased alternation as vit_pk.hip; renormalisation (state 0 > 150 -> psubusb 63, every second
-//   step) is v_readfirstlane + two scalar instructions + one v_sub_u16 clamp.
+// * n = min3(own + M, partner + (63-M), 255) on plain 32-bit values (= paddusb + pminub: the clamp commutes with
+//   the min); renormalisation (state 0 > 150 -> psubusb 63, every second step) is v_cmp + s_bitcmp1 + s_cselect
+//   + one v_sub_u32 clamp.
 // * Decision bit (tie -> 1, deconvolve.cpp:352-374) = [survivor == the candidate that came from state i+32]: one
 //   select by a constant lane mask (the roles of "own" and "partner" swap with lane bit j) and one v_cmp_eq,
 //   shifted into a per-lane history word by ONE v_addc_co_u32 (acc = 2*acc + carry-in); one ds_write per 32 steps.
@@ -89,12 +89,9 @@ DEV u32 partner(u32 m, u32 lane) {
     }
 }
 
-// 16-bit metric arithmetic through compiler builtins (v_add_u16 clamp = paddusb on m + 0xFF00, v_sub_u16 clamp,
-// v_min_u16): the hazard recogniser must see these instructions - their results feed DPP reads in the next step.
-typedef unsigned short u16;
-DEV u32 add_sat16(u32 a, u32 b) { return __builtin_elementwise_add_sat((u16)a, (u16)b); }
-DEV u32 sub_sat16(u32 a, u32 k) { return __builtin_elementwise_sub_sat((u16)a, (u16)k); }
-DEV u32 min16(u32 a, u32 b) { return __builtin_elementwise_min((u16)a, (u16)b); }
+// Metrics are plain 32-bit values 0..255 here: measured on one wave alone (tools/probe/latchain.hip,
+// profiles/r02_lat_chain_ubench.txt) a dependent 16-bit VOP3 clamp add costs ~9 cycles, a 32-bit VOP2 add or min ~4.7,
+// and v_min3_u32 folds the 255 clamp of both candidates into the survivor select.
 
 // Decision bit of a step.  Lanes with bit J clear hold predecessor i: decision = [partner cand <= own cand]
 // (m1 <= m0, tie -> 1); lanes with bit J set hold predecessor i+32: decision = [own cand <= partner cand] (m3 <= m2,
@@ -114,26 +111,21 @@ DEV void push_decisions(u32& acc, u64 d, u32 after = 0) {
 template <int RHO, bool PENDING>
 DEV void step(u32& m, u32& acc, u64& pd, const char* tabrow, u32 toff, u32 lane) {
     constexpr int J = (5 - RHO + 6) % 6;
-    const uint2 X = *reinterpret_cast<const uint2*>(tabrow + toff);  // x: M, y: 63-M (both + 0xFF00 on even steps)
-    u32 om = add_sat16(m, X.x);
-    asm("" : "+v"(om));  // keeps the SLP vectoriser from fusing the two adds into perm + v_pk_add_u16 + SDWA ops
-    const u32 p = partner<J>(m, lane);  // after the own add: m is dead here, the in-place lane swaps need one copy only
-    u32 pm = add_sat16(p, X.y);
-    asm("" : "+v"(pm));
+    const uint2 X = *reinterpret_cast<const uint2*>(tabrow + toff);  // x: M, y: 63 - M
+    const u32 om = m + X.x;                 // candidates, NOT yet clamped (<= 255 + 63)
+    const u32 p = partner<J>(m, lane);      // after the own add: m is dead here, the in-place lane swaps need one copy only
+    const u32 pm = p + X.y;
     if constexpr (PENDING) push_decisions(acc, pd, pm);  // not before this step's adds have been issued
-    const u32 n = min16(om, pm);
-    const u32 hi = ((lane >> J) & 1u) ? om : pm;  // v_cndmask with a constant lane mask
-    pd = __builtin_amdgcn_ballot_w64((u16)n == (u16)hi);
+    const u32 n = min(min(om, pm), 255u);  // v_min3_u32: the survivor with paddusb's clamp, min(min(om,255), min(pm,255))
+    const u32 hi = ((lane >> J) & 1u) ? om : pm;         // the candidate from state i+32 (v_cndmask, constant lane mask)
+    pd = __builtin_amdgcn_ballot_w64(min(hi, 255u) == n);
     if constexpr (RHO & 1) {
-        // Renormalize256 (deconvolve.cpp:407-412): state 0 = lane 0; n = m + 0xFF00 here
+        // Renormalize256 (deconvolve.cpp:407-412): state 0 = lane 0
         // (compare in every lane, take lane 0's bit: one hop shorter than v_readfirstlane + scalar compare)
-        const u64 gt = __builtin_amdgcn_ballot_w64((u16)n > (u16)(0xFF00u + 150u));
+        const u64 gt = __builtin_amdgcn_ballot_w64(n > 150u);
         u32 K;
-        asm("s_bitcmp1_b32 %1, 0\n\ts_cselect_b32 %0, %2, %3"
-            : "=s"(K)
-            : "s"((u32)gt), "s"(0xFF00u + 63u), "s"(0xFF00u)
-            : "scc");
-        m = sub_sat16(n, K);  // -> 0-based; the next (even) step's table entry carries the +0xFF00
+        asm("s_bitcmp1_b32 %1, 0\n\ts_cselect_b32 %0, 63, 0" : "=s"(K) : "s"((u32)gt) : "scc");
+        m = __builtin_elementwise_sub_sat(n, K);  // psubusb
     } else {
         m = n;
     }
@@ -244,8 +236,6 @@ __global__ __launch_bounds__(64) void vit_lat_kernel(const uint8_t* __restrict__
             const u32 s = t < T ? symb[t] : 0u;  // steps past the frame's end: run, never traced back
             u32 lo, hi;
             met8(s, lo, hi);
-            const u32 bias = (t & 1u) ? 0u : 0xFF00u;  // even steps re-bias the 0-based metrics
-            const u32 b63 = bias + 63u;
             u32 M[8];
 #pragma unroll
             for (int c = 0; c < 4; c++) {
@@ -254,8 +244,7 @@ __global__ __launch_bounds__(64) void vit_lat_kernel(const uint8_t* __restrict__
             }
             uint4* dst = reinterpret_cast<uint4*>(tab + row * 64u);
 #pragma unroll
-            for (int c = 0; c < 8; c += 2)
-                dst[c >> 1] = make_uint4(bias + M[c], b63 - M[c], bias + M[c + 1], b63 - M[c + 1]);
+            for (int c = 0; c < 8; c += 2) dst[c >> 1] = make_uint4(M[c], 63u - M[c], M[c + 1], 63u - M[c + 1]);
         };
         const u32 nch = (T + CHUNK - 1u) / CHUNK;
         for (u32 ch = 0; ch < nch; ch++) {

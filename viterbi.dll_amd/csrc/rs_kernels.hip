@@ -76,6 +76,23 @@ constexpr GenTable make_gen_table() {
 }
 __constant__ GenTable g_gen = make_gen_table();
 
+// Q[c] = a solution y of y^2 + y = c in GF(2^8) (the other one is y ^ 1), 0 when there is none (trace(c) = 1) or
+// c = 0: the closed form behind the degree-2 locator roots (Chien's 255-step scan is for degrees above 2 only).
+struct QuadTable {
+    uint8_t q[256];
+};
+constexpr QuadTable make_quad_table() {
+    const GfTables t = make_tables();
+    QuadTable Q{};
+    for (int y = 2; y < 256; y++) {
+        const int y2 = t.ato[(2 * t.iof[y]) % 255];
+        const int c = y2 ^ y;
+        if (Q.q[c] == 0) Q.q[c] = (uint8_t)y;
+    }
+    return Q;
+}
+__constant__ QuadTable g_quad = make_quad_table();
+
 __device__ __forceinline__ uint32_t mod255(uint32_t x) { return (x * 0x1010102u) >> 24; }
 
 // Chien search over i = 1..255 for a wave whose locator polynomials all have degree <= D
@@ -114,7 +131,8 @@ __device__ __forceinline__ void chien(uint32_t (&c)[NROOTS + 1], uint32_t (&root
 // worst column of the wave; wave-uniform guards (__any, the wave's largest locator degree) skip the
 // terms that are zero in every lane - after a few single-symbol errors that is most of them.
 __device__ int rs_correct(uint32_t (&s)[NROOTS], uint8_t* col, uint32_t stride, const uint8_t* __restrict__ ato,
-                          const uint8_t* __restrict__ iof, const uint8_t* __restrict__ mulp) {
+                          const uint8_t* __restrict__ iof, const uint8_t* __restrict__ mulp,
+                          const uint8_t* __restrict__ qsol) {
 #pragma unroll
     for (int i = 0; i < NROOTS; i++) s[i] = iof[s[i]];  // index form (s[10] of the reference is never used)
 
@@ -195,12 +213,37 @@ __device__ int rs_correct(uint32_t (&s)[NROOTS], uint8_t* col, uint32_t stride, 
             root[0] = (uint32_t)NN - lam[1];
             count = 1;
         }
+    } else if (dmax <= 2) {
+        // Degree 2 in closed form: 1 + l1 x + l2 x^2 = 0 with x = (l1/l2) y becomes y^2 + y = l2 / l1^2; its solutions
+        // y0, y0 ^ 1 come from a 256-byte table, the Chien index of a root x is log x (0 -> 255).  No solution, or l1 = 0
+        // (a double root, which the scan counts once): count stays below the degree and the column fails, as in the scan.
+        // Two symbol errors in a column are what is left of the decoder's longer bursts; the 255-step scan made every such
+        // wave - and, through the barriers, its whole workgroup - several times slower than its neighbours.
+        if (deg_lambda == 1) {
+            root[0] = (uint32_t)NN - lam[1];
+            count = 1;
+        } else if (deg_lambda == 2) {
+            if (lam[1] != NN) {
+                const uint32_t y0 = qsol[ato[mod255(lam[2] + 2u * (NN - lam[1]))]];
+                if (y0) {
+                    const uint32_t scale = lam[1] + NN - lam[2];  // log(l1 / l2) + 255
+                    uint32_t r0 = mod255(scale + iof[y0]), r1 = mod255(scale + iof[y0 ^ 1u]);
+                    r0 = r0 ? r0 : (uint32_t)NN;
+                    r1 = r1 ? r1 : (uint32_t)NN;
+                    root[0] = r0 < r1 ? r0 : r1;  // the scan finds them in increasing order
+                    root[1] = r0 < r1 ? r1 : r0;
+                    count = 2;
+                }
+            } else {
+                // x^2 = 1 / l2: one root (every element of GF(2^8) has exactly one square root), counted once
+                count = 1;
+            }
+        }
     } else {
         uint32_t c[NROOTS + 1];
 #pragma unroll
         for (int i = 0; i <= NROOTS; i++) c[i] = lam[i] == NN ? 0u : (uint32_t)ato[lam[i]];
-        if (dmax <= 2) chien<2>(c, root, count, deg_lambda, mulp);
-        else if (dmax <= 3) chien<3>(c, root, count, deg_lambda, mulp);
+        if (dmax <= 3) chien<3>(c, root, count, deg_lambda, mulp);
         else if (dmax <= 5) chien<5>(c, root, count, deg_lambda, mulp);
         else chien<NROOTS>(c, root, count, deg_lambda, mulp);
     }
@@ -246,7 +289,7 @@ __device__ int rs_correct(uint32_t (&s)[NROOTS], uint8_t* col, uint32_t stride, 
 // Transposed-LDS front end (codeword byte k at col[k * RS_THREADS]): Horner syndromes (rschecksf.cpp:212-219)
 // with per-root product tables (mulp[i][x] = x * alpha^i: one LDS byte per multiply-add).
 __device__ int decode_rs(uint8_t* col, const uint8_t* __restrict__ ato, const uint8_t* __restrict__ iof,
-                         const uint8_t* __restrict__ mulp) {
+                         const uint8_t* __restrict__ mulp, const uint8_t* __restrict__ qsol) {
     uint32_t s[NROOTS];
     const uint32_t d0 = col[0];
 #pragma unroll
@@ -261,7 +304,7 @@ __device__ int decode_rs(uint8_t* col, const uint8_t* __restrict__ ato, const ui
 #pragma unroll
     for (int i = 0; i < NROOTS; i++) syn |= s[i];
     if (!syn) return 0;
-    return rs_correct(s, col, RS_THREADS, ato, iof, mulp);
+    return rs_correct(s, col, RS_THREADS, ato, iof, mulp, qsol);
 }
 
 struct __attribute__((aligned(16))) G3 {
@@ -271,7 +314,7 @@ struct __attribute__((aligned(16))) G3 {
 // r <- r*x + d_k - r_9*(x^10 + g(x)): one 16-byte lookup of the feedback byte per data byte.
 __device__ int decode_rs_lfsr(uint8_t* col, uint32_t stride, const uint8_t* __restrict__ ato,
                               const uint8_t* __restrict__ iof, const uint8_t* __restrict__ mulp,
-                              const uint32_t* __restrict__ gtab) {
+                              const uint32_t* __restrict__ gtab, const uint8_t* __restrict__ qsol) {
     uint32_t r0 = 0, r1 = 0, r2 = 0;  // coefficient r_j = byte j of the 80-bit register (r2 above bit 15: junk)
     const uint8_t* q = col;
 #pragma unroll 8
@@ -300,7 +343,7 @@ __device__ int decode_rs_lfsr(uint8_t* col, uint32_t stride, const uint8_t* __re
         for (int j = NROOTS - 2; j >= 0; j--) v = c[j] ^ mulp[i * 256 + v];
         s[i] = v;
     }
-    return rs_correct(s, col, stride, ato, iof, mulp);
+    return rs_correct(s, col, stride, ato, iof, mulp, qsol);
 }
 
 // General form (used for rsdims > 256).  Workgroup = 256 lanes.  For rsdims <= 256 it takes spb = 256/rsdims
@@ -313,12 +356,14 @@ __global__ __launch_bounds__(RS_THREADS) void rs_kernel_wide(const uint8_t* __re
     __shared__ uint8_t ato[768];
     __shared__ uint8_t iof[256];
     __shared__ uint8_t mulp[(NROOTS + 1) * 256];  // mulp[i][x] = x * alpha^i, i = 0..10
+    __shared__ uint8_t qsol[256];
     __shared__ int s_minfail[RS_THREADS];
     __shared__ int s_sum[RS_THREADS];
     __shared__ int s_fail[RS_THREADS];
     const int tid = threadIdx.x;
     for (int i = tid; i < 768; i += RS_THREADS) ato[i] = g_gf.ato[i];
     iof[tid] = g_gf.iof[tid];
+    qsol[tid] = g_quad.q[tid];
     for (int i = 0; i <= NROOTS; i++) mulp[i * 256 + tid] = tid ? g_gf.ato[g_gf.iof[tid] + i] : 0;
     __syncthreads();
 
@@ -345,7 +390,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_kernel_wide(const uint8_t* __re
             if (active) {
                 const uint8_t* src = p + (size_t)sf * in_sz + colidx;
                 for (int k = 0; k < NCW; k++) cw[k * RS_THREADS + tid] = src[(size_t)k * rsdims];
-                res = decode_rs(&cw[tid], ato, iof, mulp);
+                res = decode_rs(&cw[tid], ato, iof, mulp, qsol);
                 if (res < 0) atomicMin(&s_minfail[lsf], (int)colidx);
             }
             __syncthreads();
@@ -390,11 +435,13 @@ __global__ __launch_bounds__(RS_THREADS, 4) void rs_kernel(const uint8_t* __rest
     __shared__ uint8_t ato[768];
     __shared__ uint8_t iof[256];
     __shared__ uint8_t mulp[(NROOTS + 1) * 256];  // mulp[i][x] = x * alpha^i, i = 0..10
+    __shared__ uint8_t qsol[256];                 // with it the kernel uses 40960 B of LDS: exactly four workgroups per CU
     __shared__ int s_minfail[RS_THREADS];
     __shared__ int s_sum[RS_THREADS];
     const uint32_t tid = threadIdx.x;
     for (uint32_t i = tid; i < 768; i += RS_THREADS) ato[i] = g_gf.ato[i];
     iof[tid] = g_gf.iof[tid];
+    qsol[tid] = g_quad.q[tid];
     for (int i = 0; i <= NROOTS; i++) mulp[i * 256 + tid] = tid ? g_gf.ato[g_gf.iof[tid] + i] : 0;
     for (uint32_t i = tid; i < 256u * 4u; i += RS_THREADS) gtab[i] = g_gen.w[i];
     __syncthreads();
@@ -445,7 +492,7 @@ __global__ __launch_bounds__(RS_THREADS, 4) void rs_kernel(const uint8_t* __rest
         const bool active = lsf < nloc;
         int res = 0;
         if (active) {
-            res = decode_rs_lfsr(cw + lsf * in_sz + colidx, rsdims, ato, iof, mulp, gtab);
+            res = decode_rs_lfsr(cw + lsf * in_sz + colidx, rsdims, ato, iof, mulp, gtab, qsol);
             if (res < 0) atomicMin(&s_minfail[lsf], (int)colidx);
         }
         __syncthreads();

@@ -99,3 +99,15 @@ def test_bench_through_its_spawn_path(torch_cuda):
     assert r["n_gpus"] == 1 and r["value"] > 1000
     r = _bench(["--gpus", "1", "--frames", "8192", "--mode", "multi", "--chunk-frames", "1024", "--loopback"])
     assert r["n_gpus"] == 1 and r["value"] > 500 and r["multi_matches_single_launch"] is True
+
+
+def test_device_index_out_of_range_fails_loudly(torch_cuda):
+    """VITERBI_AMD_DEVICE beyond the usable gfx950 devices: no silent fall-back to another GPU (round-1 advisor finding)"""
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np, _vitpkg; V = _vitpkg.load_package();"
+            "rc, out = V.deconvolve(768, np.full(4 * 774, 128, np.uint32));"
+            "print('RESULT', rc, V.device_count(), V.GetCPUCaps(), V.last_error())" % ROOT)
+    env = dict(os.environ, VITERBI_AMD_DEVICE="63")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")][0]
+    assert line.startswith("RESULT 1 ") and "out of range" in line, line

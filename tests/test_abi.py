@@ -86,3 +86,17 @@ def test_call_log_env(tmp_path):
     assert "deconvolve" in lines[0] and "size: 768" in lines[0] and "ret:" in lines[0]
     assert "size: 0" in lines[1] and lines[1].rstrip().endswith("ret: 0")
     assert "RScheckSuperframe" in lines[2] and "size: 4" in lines[2]
+
+
+def test_ingest_stage_environment_knobs():
+    """VITERBI_AMD_BATCH_WINDOW_US / VITERBI_AMD_BATCH_MIN_CALLERS configure the ingest stage for hosts that bind only the
+    five reference exports (read once, when the library is loaded); the setters return the previous value"""
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import _vitpkg; V = _vitpkg.load_package();"
+            "print('RESULT', V.set_batch_window_us(0), V.set_batch_min_callers(8))" % ROOT)
+    env = dict(os.environ, VITERBI_AMD_BATCH_WINDOW_US="75", VITERBI_AMD_BATCH_MIN_CALLERS="12")
+    out = subprocess.check_output([sys.executable, "-c", code], env=env, text=True)
+    assert "RESULT 75 12" in out
+    out = subprocess.check_output([sys.executable, "-c", code],
+                                  env={k: v for k, v in os.environ.items() if not k.startswith("VITERBI_AMD_BATCH")}, text=True)
+    assert "RESULT 0 8" in out

@@ -266,6 +266,18 @@ struct Batcher {
     int committed = 0;                // callers that chose the batch path and are not in a batch yet (under mu)
     bool started = false;
     static constexpr size_t MAX_BATCH = 256;
+    Batcher() {
+        // a host that only binds the five reference exports configures the stage through the environment
+        // (the analogue of the reference's viterbi.txt): window in microseconds (0 = off) and the engagement threshold
+        if (const char* e = getenv("VITERBI_AMD_BATCH_WINDOW_US")) {
+            const int w = atoi(e);
+            window_us.store(w < 0 ? 0 : w > 100000 ? 100000 : w);
+        }
+        if (const char* e = getenv("VITERBI_AMD_BATCH_MIN_CALLERS")) {
+            const int n = atoi(e);
+            min_callers.store(n < 1 ? 1 : n);
+        }
+    }
     std::vector<vit_frame_desc> h_desc;
     void* d_desc = nullptr; size_t ddesc_cap = 0;
 

@@ -195,7 +195,17 @@ DEV void acs_step(u32& A, u32& B, u32& acc0, u32& acc1, u32 mt, u32 lane, const 
         const u32 z = (u32)__builtin_amdgcn_ds_swizzle((int)W(n0), 0);  // lane 0 of each 32-lane group
 #endif
         exchange<4 - RHO>(A, B, W(n0), W(n1), lane);
-#if VIT_K3
+#if VIT_K3 == 2
+        // v_add_u32 (2.7 cycles; bit 15 of each half := m >= 151), v_pk_ashrrev_i16 15, v_and_or_b32
+        u32 K;
+        {
+            const u32 w = z + 0x80688069u;
+            asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]\n\t"
+                "v_and_or_b32 %0, %0, %2, %3"
+                : "=&v"(K)
+                : "v"(w), "s"(0x003F003Fu), "v"(C.hi));
+        }
+#elif VIT_K3
         // three instructions: v_pk_add_u16 (bit 15 of each half := m >= 151), v_pk_ashrrev_i16 15, v_and_or_b32
         u32 K;
         asm("v_pk_add_u16 %0, %1, %2\n\t"

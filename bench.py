@@ -358,7 +358,9 @@ def main(argv=None):
             got = (d_out if in_shard_mode else d_all_out).cpu().numpy()
             bad = int((got != ref).any(axis=1).sum())
             result["cpu_baseline"] = base
-            result["parity"] = {"frames_checked": n, "frames_differing": bad, "bit_exact": bad == 0}
+            result["parity"] = {"frames_checked": n, "frames_differing": bad, "bit_exact": bad == 0,
+                                "checker": "this repo's own port of the reference's integer specification (oracle/, "
+                                           "'parity unpinned' beyond SURVEY 8c's KATs - DESIGN.md (c)), not the reference binary"}
             result["speedup_vs_cpu_1thread"] = round(result["value"] / base["value"], 1)
             if bad:
                 result["value"] = 0.0  # a fast kernel with wrong results is not a result

@@ -16,7 +16,11 @@ for s in range(base_n):
         cw = O.rs_encode(rng.integers(0, 256, 110, dtype=np.uint8))
         # clean: no errors; light: one symbol error in 6 % of the columns (what Eb/N0 = 3 dB leaves behind);
         # mixed: errors in 5/9 of the columns incl. uncorrectable ones
-        ne = 0 if mode == "clean" else (int(rng.random() < 0.06) if mode == "light" else int(rng.choice([0, 0, 0, 0, 1, 2, 3, 5, 6])))
+        # le2 / le3 / le5: 0..2, 0..3, 0..5 errors per column, all correctable (what the error path costs by locator degree)
+        if mode == "clean": ne = 0
+        elif mode == "light": ne = int(rng.random() < 0.06)
+        elif mode in ("le2", "le3", "le5"): ne = int(rng.integers(0, int(mode[2]) + 1))
+        else: ne = int(rng.choice([0, 0, 0, 0, 1, 2, 3, 5, 6]))
         pos = rng.choice(120, ne, replace=False); cw[pos] ^= rng.integers(1, 256, ne, dtype=np.uint8)
         p[s, :, j] = cw
 p = p.reshape(base_n, -1)

@@ -25,9 +25,11 @@ constexpr int NROOTS = 10;   // viterbi.h:97
 constexpr int PADN = 135;    // rschecksf.cpp:45
 constexpr int NCW = 120, NMSG = 110;
 constexpr int RS_THREADS = 256;
+constexpr int ATO_ZERO = 512;   // index form of a zero coefficient where a lookup must give 0: ato[512..607] = 0
+constexpr int ATO_SIZE = 608;
 
 struct GfTables {
-    uint8_t ato[768];  // alpha_to[i % 255], viterbi.h:101-105
+    uint8_t ato[ATO_SIZE];  // alpha_to[i % 255] for i < 512 (viterbi.h:101-105), zeros from ATO_ZERO on
     uint8_t iof[256];  // index_of, index_of[0] = 255
 };
 constexpr GfTables make_tables() {
@@ -42,13 +44,31 @@ constexpr GfTables make_tables() {
         if (sr & 256) sr ^= 285;  // c_gfpoly, viterbi.h:96
         sr &= NN;
     }
-    for (int i = 0; i < 768; i++) t.ato[i] = alpha[i % 255];
+    for (int i = 0; i < ATO_ZERO; i++) t.ato[i] = alpha[i % 255];
     return t;
 }
 __constant__ GfTables g_gf = make_tables();
 
+// Q[c] = a solution y of y^2 + y = c in GF(2^8) (the other one is y ^ 1), 0 when there is none (trace(c) = 1) or
+// c = 0: the closed form behind the degree-2 locator roots (Chien's 255-step scan is for degrees above 2 only).
+struct QuadTable {
+    uint8_t q[256];
+};
+constexpr QuadTable make_quad_table() {
+    const GfTables t = make_tables();
+    QuadTable Q{};
+    for (int y = 2; y < 256; y++) {
+        const int y2 = t.ato[(2 * t.iof[y]) % 255];
+        const int c = y2 ^ y;
+        if (Q.q[c] == 0) Q.q[c] = (uint8_t)y;
+    }
+    return Q;
+}
+
 // G[x] = (x*g_0, ..., x*g_9) packed little-endian into 16 bytes, g(x) = prod_{i=0..9}(x + alpha^i)
-// (monic, degree 10): the feedback table of the remainder LFSR.
+// (monic, degree 10): the feedback table of the remainder LFSR.  The six spare bytes of a row are used too (LDS is what
+// limits the kernel to four workgroups per CU): byte 10 = Q[x] (the LFSR ignores the upper half of dword 2), dword 3 of
+// rows 0..127 / 128..255 = the per-superframe first-failure / correction-count words of rs_kernel.
 struct GenTable {
     uint32_t w[256 * 4];
 };
@@ -72,54 +92,101 @@ constexpr GenTable make_gen_table() {
             const uint32_t prod = g[j] ? t.ato[t.iof[x] + t.iof[g[j]]] : 0u;
             G.w[x * 4 + j / 4] |= prod << (8 * (j % 4));
         }
+    const QuadTable Q = make_quad_table();
+    for (int x = 0; x < 256; x++) G.w[x * 4 + 2] |= (uint32_t)Q.q[x] << 16;
     return G;
 }
 __constant__ GenTable g_gen = make_gen_table();
 
-// Q[c] = a solution y of y^2 + y = c in GF(2^8) (the other one is y ^ 1), 0 when there is none (trace(c) = 1) or
-// c = 0: the closed form behind the degree-2 locator roots (Chien's 255-step scan is for degrees above 2 only).
-struct QuadTable {
-    uint8_t q[256];
+// Four Chien steps per lookup: W[j-1][c] = (c*a^j, c*a^2j, c*a^3j, c*a^4j) packed little-endian, j = 1..5 (a = alpha).
+constexpr int STEP_TERMS = 5;
+struct StepTable {
+    uint32_t w[STEP_TERMS * 256];
 };
-constexpr QuadTable make_quad_table() {
+constexpr StepTable make_step_table() {
     const GfTables t = make_tables();
-    QuadTable Q{};
-    for (int y = 2; y < 256; y++) {
-        const int y2 = t.ato[(2 * t.iof[y]) % 255];
-        const int c = y2 ^ y;
-        if (Q.q[c] == 0) Q.q[c] = (uint8_t)y;
-    }
-    return Q;
+    StepTable S{};
+    for (int j = 1; j <= STEP_TERMS; j++)
+        for (int c = 1; c < 256; c++)
+            for (int k = 1; k <= 4; k++) S.w[(j - 1) * 256 + c] |= (uint32_t)t.ato[t.iof[c] + j * k] << (8 * (k - 1));
+    return S;
 }
-__constant__ QuadTable g_quad = make_quad_table();
+__constant__ StepTable g_step = make_step_table();
 
 __device__ __forceinline__ uint32_t mod255(uint32_t x) { return (x * 0x1010102u) >> 24; }
 
-// Chien search over i = 1..255 for a wave whose locator polynomials all have degree <= D
-// (rschecksf.cpp:299-320): the reference advances the logs b[j] += j and sums alpha_to[b[j]]; here the
-// same terms lambda_j * alpha^(j*i) are kept in polynomial form and advanced with the product tables
-// (one LDS byte per term, no mod-255 arithmetic).  Terms above D are zero in every lane.
-template <int D>
-__device__ __forceinline__ void chien(uint32_t (&c)[NROOTS + 1], uint32_t (&root)[NROOTS], int& count, int deg_lambda,
-                                      const uint8_t* __restrict__ mulp) {
-    bool searching = true;
+// Chien search over i = 1..255 (rschecksf.cpp:299-320) in the reference's own form - the logs b[j] advance by j, the sum
+// is over alpha_to[b[j]] - for the rare wave that holds a locator above degree 5 (never correctable, but its roots are
+// counted).  Roots go to the column's parity rows like chien_quad's.  Lanes with need == false find nothing.
+__device__ __forceinline__ int chien_log(const uint32_t (&lam)[NROOTS + 1], bool need, int deg_lambda, uint8_t* col,
+                                         uint32_t stride, const uint8_t* __restrict__ ato) {
+    uint32_t b[NROOTS + 1], live[NROOTS + 1];
+#pragma unroll
+    for (int j = 1; j <= NROOTS; j++) {
+        live[j] = need && lam[j] != NN ? 0xFFu : 0u;
+        b[j] = live[j] ? lam[j] : 0u;
+    }
+    bool searching = need;
+    int count = 0;
     for (int i = 1; i <= NN; i++) {
         if (searching) {
             uint32_t q = 1;  // lambda[0] is always 1
 #pragma unroll
-            for (int j = D; j > 0; j--) {
-                c[j] = mulp[j * 256 + c[j]];
-                q ^= c[j];
+            for (int j = 1; j <= NROOTS; j++) {
+                b[j] += (uint32_t)j;
+                b[j] = b[j] < (uint32_t)NN ? b[j] : b[j] - NN;
+                q ^= ato[b[j]] & live[j];
             }
             if (q == 0) {
-#pragma unroll
-                for (int k = 0; k < D; k++)
-                    if (count == k) root[k] = (uint32_t)i;
+                col[(uint32_t)(NMSG + count) * stride] = (uint8_t)i;
                 if (++count == deg_lambda) searching = false;
             }
         }
         if (!__any(searching)) break;
     }
+    return count;
+}
+
+// The same search four positions per lookup, for locators of degree <= D <= 5 (the 255 dependent byte lookups per term of
+// the loop above kept the LDS busy for most of the error path: 0.63 ms of the 1.01 ms a batch with three-error
+// columns took).  adr[j] = 4 * lambda_j * alpha^(j*i0): one dword of the step table gives the term at i0+1..i0+4 and
+// the next address; the XOR of the terms' dwords evaluates the locator at four positions at once, a zero byte is a root.
+// Roots go to the column's parity rows (rows 110..119 are dead once the syndromes are known and are never output).
+// Lanes with need == false carry zero terms and find nothing.  Returns the number of roots in 1..255.
+template <int D>
+__device__ __forceinline__ int chien_quad(const uint32_t (&lam)[NROOTS + 1], bool need, uint8_t* col, uint32_t stride,
+                                          const uint8_t* __restrict__ ato, const uint32_t* __restrict__ step) {
+    static_assert(D <= STEP_TERMS, "step table");
+    uint32_t adr[D + 1];
+#pragma unroll
+    for (int j = 1; j <= D; j++) adr[j] = need && lam[j] != NN ? (uint32_t)ato[lam[j]] << 2 : 0u;  // lam[] in index form
+    int count = 0;
+    for (int blk = 0; blk < 8; blk++) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            uint32_t q = 0x01010101u;  // lambda_0 = 1 at each of the four positions
+#pragma unroll
+            for (int j = 1; j <= D; j++) {
+                const uint32_t t =
+                    *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(step) + (j - 1) * 1024 + adr[j]);
+                q ^= t;
+                adr[j] = (t >> 22) & 0x3FCu;
+            }
+            const uint32_t z = ~(((q & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | q | 0x7F7F7F7Fu);  // 0x80 exactly where a byte is 0
+            m = (m >> 1) | z;  // step `it`, byte k ends up in bit 8k + it
+        }
+        if (blk == 7) m &= 0x7FFFFFFFu;  // position 256 = position 1 again
+        if (__any(m != 0)) {
+            while (m) {
+                const uint32_t bit = (uint32_t)__ffs((int)m) - 1u;
+                m &= m - 1u;
+                col[(uint32_t)(NMSG + count) * stride] = (uint8_t)(32u * blk + 4u * (bit & 7u) + (bit >> 3) + 1u);  // ascending
+                count++;
+            }
+        }
+    }
+    return count;
 }
 
 // Everything after the syndromes: s[] = the ten syndromes in polynomial form, not all zero.
@@ -130,9 +197,10 @@ __device__ __forceinline__ void chien(uint32_t (&c)[NROOTS + 1], uint32_t (&root
 // A wavefront runs this path as soon as ONE of its 64 columns has an error, so its cost is set by the
 // worst column of the wave; wave-uniform guards (__any, the wave's largest locator degree) skip the
 // terms that are zero in every lane - after a few single-symbol errors that is most of them.
+// qrow = byte 10 of the generator table's row 0: Q[x] is qrow[16 * x].
 __device__ int rs_correct(uint32_t (&s)[NROOTS], uint8_t* col, uint32_t stride, const uint8_t* __restrict__ ato,
-                          const uint8_t* __restrict__ iof, const uint8_t* __restrict__ mulp,
-                          const uint8_t* __restrict__ qsol) {
+                          const uint8_t* __restrict__ iof, const uint8_t* __restrict__ qrow,
+                          const uint32_t* __restrict__ step) {
 #pragma unroll
     for (int i = 0; i < NROOTS; i++) s[i] = iof[s[i]];  // index form (s[10] of the reference is never used)
 
@@ -207,45 +275,44 @@ __device__ int rs_correct(uint32_t (&s)[NROOTS], uint8_t* col, uint32_t stride, 
 #pragma unroll
     for (int k = 0; k < NROOTS; k++) root[k] = 0;
     int count = 0;
-    if (dmax <= 1) {
-        // 1 + lambda_1 * alpha^i = 0 has exactly one solution in i = 1..255: i = 255 - log(lambda_1)
-        if (deg_lambda == 1) {
-            root[0] = (uint32_t)NN - lam[1];
-            count = 1;
-        }
-    } else if (dmax <= 2) {
-        // Degree 2 in closed form: 1 + l1 x + l2 x^2 = 0 with x = (l1/l2) y becomes y^2 + y = l2 / l1^2; its solutions
-        // y0, y0 ^ 1 come from a 256-byte table, the Chien index of a root x is log x (0 -> 255).  No solution, or l1 = 0
-        // (a double root, which the scan counts once): count stays below the degree and the column fails, as in the scan.
-        // Two symbol errors in a column are what is left of the decoder's longer bursts; the 255-step scan made every such
-        // wave - and, through the barriers, its whole workgroup - several times slower than its neighbours.
-        if (deg_lambda == 1) {
-            root[0] = (uint32_t)NN - lam[1];
-            count = 1;
-        } else if (deg_lambda == 2) {
-            if (lam[1] != NN) {
-                const uint32_t y0 = qsol[ato[mod255(lam[2] + 2u * (NN - lam[1]))]];
-                if (y0) {
-                    const uint32_t scale = lam[1] + NN - lam[2];  // log(l1 / l2) + 255
-                    uint32_t r0 = mod255(scale + iof[y0]), r1 = mod255(scale + iof[y0 ^ 1u]);
-                    r0 = r0 ? r0 : (uint32_t)NN;
-                    r1 = r1 ? r1 : (uint32_t)NN;
-                    root[0] = r0 < r1 ? r0 : r1;  // the scan finds them in increasing order
-                    root[1] = r0 < r1 ? r1 : r0;
-                    count = 2;
-                }
-            } else {
-                // x^2 = 1 / l2: one root (every element of GF(2^8) has exactly one square root), counted once
-                count = 1;
+    // Degrees 1 and 2 in closed form, whatever the rest of the wave needs.
+    // Degree 1: 1 + lambda_1 * alpha^i = 0 has exactly one solution in i = 1..255: i = 255 - log(lambda_1).
+    // Degree 2: 1 + l1 x + l2 x^2 = 0 with x = (l1/l2) y becomes y^2 + y = l2 / l1^2; its solutions y0, y0 ^ 1 come from a
+    // 256-byte table, the Chien index of a root x is log x (0 -> 255).  No solution, or l1 = 0 (a double root, which the
+    // scan counts once): count stays below the degree and the column fails, as in the scan.
+    // Two symbol errors in a column are what is left of the decoder's longer bursts; a 255-step scan would make every such
+    // wave - and, through the barriers, its whole workgroup - several times slower than its neighbours.
+    if (deg_lambda == 1) {
+        root[0] = (uint32_t)NN - lam[1];
+        count = 1;
+    } else if (dmax >= 2 && deg_lambda == 2) {
+        if (lam[1] != NN) {
+            const uint32_t y0 = qrow[16u * ato[mod255(lam[2] + 2u * (NN - lam[1]))]];
+            if (y0) {
+                const uint32_t scale = lam[1] + NN - lam[2];  // log(l1 / l2) + 255
+                uint32_t r0 = mod255(scale + iof[y0]), r1 = mod255(scale + iof[y0 ^ 1u]);
+                r0 = r0 ? r0 : (uint32_t)NN;
+                r1 = r1 ? r1 : (uint32_t)NN;
+                root[0] = r0 < r1 ? r0 : r1;  // the scan finds them in increasing order
+                root[1] = r0 < r1 ? r1 : r0;
+                count = 2;
             }
+        } else {
+            // x^2 = 1 / l2: one root (every element of GF(2^8) has exactly one square root), counted once
+            count = 1;
         }
-    } else {
-        uint32_t c[NROOTS + 1];
+    }
+    if (dmax >= 3) {  // the scan, for the lanes of degree 3 and above
+        const bool need = deg_lambda >= 3;
+        const int found = dmax <= 3            ? chien_quad<3>(lam, need, col, stride, ato, step)
+                          : dmax <= STEP_TERMS ? chien_quad<STEP_TERMS>(lam, need, col, stride, ato, step)
+                                               : chien_log(lam, need, deg_lambda, col, stride, ato);
+        if (need) {
+            count = found;
 #pragma unroll
-        for (int i = 0; i <= NROOTS; i++) c[i] = lam[i] == NN ? 0u : (uint32_t)ato[lam[i]];
-        if (dmax <= 3) chien<3>(c, root, count, deg_lambda, mulp);
-        else if (dmax <= 5) chien<5>(c, root, count, deg_lambda, mulp);
-        else chien<NROOTS>(c, root, count, deg_lambda, mulp);
+            for (int k = 0; k < NROOTS; k++)
+                if (k < dmax && k < found) root[k] = col[(uint32_t)(NMSG + k) * stride];
+        }
     }
     if (deg_lambda != count) return -1;
 
@@ -278,8 +345,8 @@ __device__ int rs_correct(uint32_t (&s)[NROOTS], uint8_t* col, uint32_t stride, 
 #pragma unroll
                 for (int i = 0; i < NROOTS; i += 2)
                     if (i < dmax && i <= top && lam[i + 1] != NN) den ^= ato[mod255(lam[i + 1] + i * rt)];
-                const uint32_t tmp = (uint32_t)iof[num1] + iof[num2] + (NN - iof[den]);  // <= 763 < 768
-                col[(rt - 1 - PADN) * stride] ^= ato[tmp];
+                const uint32_t tmp = (uint32_t)iof[num1] + iof[num2] + (NN - iof[den]);  // <= 763
+                col[(rt - 1 - PADN) * stride] ^= ato[mod255(tmp)];
             }
         }
     }
@@ -289,7 +356,8 @@ __device__ int rs_correct(uint32_t (&s)[NROOTS], uint8_t* col, uint32_t stride, 
 // Transposed-LDS front end (codeword byte k at col[k * RS_THREADS]): Horner syndromes (rschecksf.cpp:212-219)
 // with per-root product tables (mulp[i][x] = x * alpha^i: one LDS byte per multiply-add).
 __device__ int decode_rs(uint8_t* col, const uint8_t* __restrict__ ato, const uint8_t* __restrict__ iof,
-                         const uint8_t* __restrict__ mulp, const uint8_t* __restrict__ qsol) {
+                         const uint8_t* __restrict__ mulp, const uint8_t* __restrict__ qrow,
+                         const uint32_t* __restrict__ step) {
     uint32_t s[NROOTS];
     const uint32_t d0 = col[0];
 #pragma unroll
@@ -304,7 +372,7 @@ __device__ int decode_rs(uint8_t* col, const uint8_t* __restrict__ ato, const ui
 #pragma unroll
     for (int i = 0; i < NROOTS; i++) syn |= s[i];
     if (!syn) return 0;
-    return rs_correct(s, col, RS_THREADS, ato, iof, mulp, qsol);
+    return rs_correct(s, col, RS_THREADS, ato, iof, qrow, step);
 }
 
 struct __attribute__((aligned(16))) G3 {
@@ -313,37 +381,41 @@ struct __attribute__((aligned(16))) G3 {
 // Natural-layout front end (codeword byte k at col[k * stride]): remainder modulo g(x) by LFSR,
 // r <- r*x + d_k - r_9*(x^10 + g(x)): one 16-byte lookup of the feedback byte per data byte.
 __device__ int decode_rs_lfsr(uint8_t* col, uint32_t stride, const uint8_t* __restrict__ ato,
-                              const uint8_t* __restrict__ iof, const uint8_t* __restrict__ mulp,
-                              const uint32_t* __restrict__ gtab, const uint8_t* __restrict__ qsol) {
+                              const uint8_t* __restrict__ iof, const uint32_t* __restrict__ gtab,
+                              const uint32_t* __restrict__ step) {
     uint32_t r0 = 0, r1 = 0, r2 = 0;  // coefficient r_j = byte j of the 80-bit register (r2 above bit 15: junk)
     const uint8_t* q = col;
 #pragma unroll 8
     for (int k = 0; k < NCW; k++, q += stride) {
         const uint32_t d = *q;
         const uint32_t f = (r2 >> 8) & 0xFFu;  // r_9
-        const G3 t = *reinterpret_cast<const G3*>(gtab + f * 4u);  // ds_read_b96: 10 of the 16 bytes are payload
+        const G3 t = *reinterpret_cast<const G3*>(gtab + f * 4u);  // ds_read_b96: 10 of the 12 bytes are payload
         r2 = __builtin_amdgcn_alignbit(r2, r1, 24) ^ t.z;
         r1 = __builtin_amdgcn_alignbit(r1, r0, 24) ^ t.y;
         r0 = ((r0 << 8) | d) ^ t.x;
     }
     r2 &= 0xFFFFu;
     if ((r0 | r1 | r2) == 0) return 0;
-    // syndromes S_i = r(alpha^i) (= the reference's Horner sums over the whole codeword)
-    uint32_t c[NROOTS];
-#pragma unroll
-    for (int j = 0; j < NROOTS; j++) c[j] = ((j < 4 ? r0 : j < 8 ? r1 : r2) >> (8 * (j & 3))) & 0xFFu;
+    // syndromes S_i = r(alpha^i) = sum_j r_j alpha^(i*j) (= the reference's Horner sums over the whole codeword), through
+    // the logs of the ten coefficients: independent lookups at ato[log r_j + i*j], a zero coefficient reads the zero block
+    uint32_t lg[NROOTS];
     uint32_t s[NROOTS];
     s[0] = 0;
 #pragma unroll
-    for (int j = 0; j < NROOTS; j++) s[0] ^= c[j];
+    for (int j = 0; j < NROOTS; j++) {
+        const uint32_t c = ((j < 4 ? r0 : j < 8 ? r1 : r2) >> (8 * (j & 3))) & 0xFFu;
+        s[0] ^= c;
+        lg[j] = c ? (uint32_t)iof[c] : (uint32_t)ATO_ZERO;
+    }
 #pragma unroll
     for (int i = 1; i < NROOTS; i++) {
-        uint32_t v = c[NROOTS - 1];
+        uint32_t v = 0;
 #pragma unroll
-        for (int j = NROOTS - 2; j >= 0; j--) v = c[j] ^ mulp[i * 256 + v];
+        for (int j = 0; j < NROOTS; j++) v ^= ato[lg[j] + (uint32_t)(i * j)];  // <= 512 + 81
         s[i] = v;
+        if (i % 3 == 0) __builtin_amdgcn_sched_barrier(0);  // 30 lookups in flight are plenty; all 90 cost spills
     }
-    return rs_correct(s, col, stride, ato, iof, mulp, qsol);
+    return rs_correct(s, col, stride, ato, iof, reinterpret_cast<const uint8_t*>(gtab) + 10, step);
 }
 
 // General form (used for rsdims > 256).  Workgroup = 256 lanes.  For rsdims <= 256 it takes spb = 256/rsdims
@@ -353,18 +425,20 @@ __global__ __launch_bounds__(RS_THREADS) void rs_kernel_wide(const uint8_t* __re
                                                         int32_t* __restrict__ ret, uint32_t rsdims,
                                                         long long nsf) {
     __shared__ uint8_t cw[NCW * RS_THREADS];  // [row][lane]
-    __shared__ uint8_t ato[768];
+    __shared__ uint8_t ato[ATO_SIZE];
     __shared__ uint8_t iof[256];
     __shared__ uint8_t mulp[(NROOTS + 1) * 256];  // mulp[i][x] = x * alpha^i, i = 0..10
-    __shared__ uint8_t qsol[256];
+    __shared__ uint8_t qrow[256 * 16];            // Q[x] at 16 * x, as in rs_kernel's generator table
+    __shared__ uint32_t step[STEP_TERMS * 256];
     __shared__ int s_minfail[RS_THREADS];
     __shared__ int s_sum[RS_THREADS];
     __shared__ int s_fail[RS_THREADS];
     const int tid = threadIdx.x;
-    for (int i = tid; i < 768; i += RS_THREADS) ato[i] = g_gf.ato[i];
+    for (int i = tid; i < ATO_SIZE; i += RS_THREADS) ato[i] = g_gf.ato[i];
     iof[tid] = g_gf.iof[tid];
-    qsol[tid] = g_quad.q[tid];
+    qrow[16 * tid] = (uint8_t)(g_gen.w[tid * 4 + 2] >> 16);
     for (int i = 0; i <= NROOTS; i++) mulp[i * 256 + tid] = tid ? g_gf.ato[g_gf.iof[tid] + i] : 0;
+    for (int i = tid; i < STEP_TERMS * 256; i += RS_THREADS) step[i] = g_step.w[i];
     __syncthreads();
 
     const uint32_t spb = rsdims <= RS_THREADS ? RS_THREADS / rsdims : 1u;  // superframes per pass
@@ -390,7 +464,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_kernel_wide(const uint8_t* __re
             if (active) {
                 const uint8_t* src = p + (size_t)sf * in_sz + colidx;
                 for (int k = 0; k < NCW; k++) cw[k * RS_THREADS + tid] = src[(size_t)k * rsdims];
-                res = decode_rs(&cw[tid], ato, iof, mulp, qsol);
+                res = decode_rs(&cw[tid], ato, iof, mulp, qrow, step);
                 if (res < 0) atomicMin(&s_minfail[lsf], (int)colidx);
             }
             __syncthreads();
@@ -425,28 +499,30 @@ __device__ __forceinline__ void copy_linear(uint8_t* dst, const uint8_t* src, ui
     else copy_vec<uint8_t>(dst, src, n, tid);
 }
 
-// rsdims <= 256: spb = 256/rsdims superframes per pass, natural layout in LDS (see the header comment).
-// (second launch bound: 4 waves per SIMD = 4 workgroups per CU, which is what the 40 KB of LDS allow)
+constexpr uint32_t RS_MAX_SPB = 128;  // superframes per pass of rs_kernel: the generator table has 2 x 128 spare words
+
+// rsdims <= 256: spb = min(256/rsdims, 128) superframes per pass, natural layout in LDS (see the header comment).
+// LDS: 30720 (codewords) + 4096 (generator rows, Q, the per-superframe words) + 5120 (Chien steps) + 608 + 256 = 40800 B,
+// which is what lets four workgroups share a CU (second launch bound: 4 waves per SIMD); the three-workgroup build
+// that kept every table separate was 6 % slower on clean data (profiles/r02_ab_rs_chien.txt).
 __global__ __launch_bounds__(RS_THREADS, 4) void rs_kernel(const uint8_t* __restrict__ p, uint8_t* __restrict__ out,
                                                         int32_t* __restrict__ ret, uint32_t rsdims,
                                                         long long nsf, int host_polls_ret) {
     __shared__ __attribute__((aligned(16))) uint8_t cw[NCW * RS_THREADS];  // [superframe][row][column]
     __shared__ __attribute__((aligned(16))) uint32_t gtab[256 * 4];
-    __shared__ uint8_t ato[768];
+    __shared__ uint32_t step[STEP_TERMS * 256];
+    __shared__ uint8_t ato[ATO_SIZE];
     __shared__ uint8_t iof[256];
-    __shared__ uint8_t mulp[(NROOTS + 1) * 256];  // mulp[i][x] = x * alpha^i, i = 0..10
-    __shared__ uint8_t qsol[256];                 // with it the kernel uses 40960 B of LDS: exactly four workgroups per CU
-    __shared__ int s_minfail[RS_THREADS];
-    __shared__ int s_sum[RS_THREADS];
     const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < 768; i += RS_THREADS) ato[i] = g_gf.ato[i];
+    for (uint32_t i = tid; i < ATO_SIZE; i += RS_THREADS) ato[i] = g_gf.ato[i];
     iof[tid] = g_gf.iof[tid];
-    qsol[tid] = g_quad.q[tid];
-    for (int i = 0; i <= NROOTS; i++) mulp[i * 256 + tid] = tid ? g_gf.ato[g_gf.iof[tid] + i] : 0;
     for (uint32_t i = tid; i < 256u * 4u; i += RS_THREADS) gtab[i] = g_gen.w[i];
+    for (uint32_t i = tid; i < STEP_TERMS * 256u; i += RS_THREADS) step[i] = g_step.w[i];
+    int* const s_minfail = reinterpret_cast<int*>(gtab) + 3;                    // word l: s_minfail[4 * l]
+    int* const s_sum = reinterpret_cast<int*>(gtab) + 4 * RS_MAX_SPB + 3;       //         s_sum[4 * l]
     __syncthreads();
 
-    const uint32_t spb = RS_THREADS / rsdims;
+    const uint32_t spb = RS_THREADS / rsdims < RS_MAX_SPB ? RS_THREADS / rsdims : RS_MAX_SPB;
     const long long ngroups = (nsf + spb - 1) / spb;
     const uint32_t in_sz = NCW * rsdims, out_sz = NMSG * rsdims;
     const uint32_t lsf = tid / rsdims, colidx = tid - lsf * rsdims;
@@ -474,8 +550,8 @@ __global__ __launch_bounds__(RS_THREADS, 4) void rs_kernel(const uint8_t* __rest
         const long long sf0 = g * spb;
         const uint32_t nloc = nsf - sf0 < (long long)spb ? (uint32_t)(nsf - sf0) : spb;
         if (tid < spb) {
-            s_minfail[tid] = NOFAIL;
-            s_sum[tid] = 0;
+            s_minfail[4 * tid] = NOFAIL;
+            s_sum[4 * tid] = 0;
         }
         if (pre_ok) {
             const uint32_t nw = nloc * in_sz / 8u;
@@ -492,8 +568,8 @@ __global__ __launch_bounds__(RS_THREADS, 4) void rs_kernel(const uint8_t* __rest
         const bool active = lsf < nloc;
         int res = 0;
         if (active) {
-            res = decode_rs_lfsr(cw + lsf * in_sz + colidx, rsdims, ato, iof, mulp, gtab, qsol);
-            if (res < 0) atomicMin(&s_minfail[lsf], (int)colidx);
+            res = decode_rs_lfsr(cw + lsf * in_sz + colidx, rsdims, ato, iof, gtab, step);
+            if (res < 0) atomicMin(&s_minfail[4 * lsf], (int)colidx);
         }
         __syncthreads();
         uint8_t* dst0 = out + (size_t)sf0 * out_sz;
@@ -502,26 +578,26 @@ __global__ __launch_bounds__(RS_THREADS, 4) void rs_kernel(const uint8_t* __rest
             const uint32_t wps = out_sz >> 2;  // dwords per superframe; in_sz is a multiple of 8
             for (uint32_t c = tid; c < nloc * wps; c += RS_THREADS) {
                 const uint32_t l = c / wps, o = c - l * wps;
-                if (s_minfail[l] == NOFAIL)
+                if (s_minfail[4 * l] == NOFAIL)
                     reinterpret_cast<uint32_t*>(dst0 + (size_t)l * out_sz)[o] =
                         reinterpret_cast<const uint32_t*>(cw + l * in_sz)[o];
             }
             if (active) {
-                const int mf = s_minfail[lsf];
+                const int mf = s_minfail[4 * lsf];
                 if (mf != NOFAIL && (int)colidx < mf) {  // columns before the first failure are written
                     uint8_t* dst = dst0 + (size_t)lsf * out_sz + colidx;
                     const uint8_t* src = cw + lsf * in_sz + colidx;
                     for (int k = 0; k < NMSG; k++) dst[(size_t)k * rsdims] = src[k * rsdims];
                 }
-                if ((int)colidx < mf) atomicAdd(&s_sum[lsf], res);
+                if ((int)colidx < mf) atomicAdd(&s_sum[4 * lsf], res);
             }
         } else if (active) {
-            const int mf = s_minfail[lsf];
+            const int mf = s_minfail[4 * lsf];
             if ((int)colidx < mf) {
                 uint8_t* dst = dst0 + (size_t)lsf * out_sz + colidx;
                 const uint8_t* src = cw + lsf * in_sz + colidx;
                 for (int k = 0; k < NMSG; k++) dst[(size_t)k * rsdims] = src[k * rsdims];
-                atomicAdd(&s_sum[lsf], res);
+                atomicAdd(&s_sum[4 * lsf], res);
             }
         }
         // single-call path (RScheckSuperframe): the host spins on ret[0] in its mapped buffer instead of waiting for the
@@ -529,7 +605,7 @@ __global__ __launch_bounds__(RS_THREADS, 4) void rs_kernel(const uint8_t* __rest
         if (host_polls_ret) __threadfence_system();
         __syncthreads();
         if (tid < nloc) {
-            const int32_t r = s_minfail[tid] != NOFAIL ? -1 : s_sum[tid];
+            const int32_t r = s_minfail[4 * tid] != NOFAIL ? -1 : s_sum[4 * tid];
             if (host_polls_ret) __hip_atomic_store(&ret[sf0 + tid], r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             else ret[sf0 + tid] = r;
         }
@@ -543,7 +619,8 @@ hipError_t rs_launch(const uint8_t* d_p, uint8_t* d_out, int32_t* d_ret, uint32_
                      hipStream_t stream, bool host_polls_ret) {
     if (nsf <= 0 || rsdims == 0) return hipSuccess;
     if (host_polls_ret && (nsf != 1 || rsdims > RS_THREADS)) return hipErrorInvalidValue;
-    const uint32_t spb = rsdims <= RS_THREADS ? RS_THREADS / rsdims : 1u;
+    uint32_t spb = rsdims <= RS_THREADS ? RS_THREADS / rsdims : 1u;
+    if (spb > RS_MAX_SPB) spb = RS_MAX_SPB;
     long long groups = (nsf + spb - 1) / spb;
     if (groups > (1 << 20)) groups = 1 << 20;
     if (rsdims <= RS_THREADS) {

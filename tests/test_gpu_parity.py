@@ -377,6 +377,43 @@ def test_rs_batch_parity(V, O, torch_cuda, rsdims):
     assert np.array_equal(d_out.cpu().numpy(), out_ref)
 
 
+@pytest.mark.parametrize("rsdims,weights", [
+    (24, {0: 90, 1: 5, 2: 2, 3: 1, 4: 1, 6: 1}),            # a few high-degree columns per wave, some uncorrectable
+    (24, {0: 40, 1: 10, 2: 10, 3: 15, 5: 15, 6: 8, 9: 2}),  # about a third of the lanes, failures end superframes early
+    (24, {3: 30, 4: 30, 5: 38, 7: 2}),                      # every lane
+    (4, {0: 70, 2: 10, 3: 10, 5: 5, 6: 5}),                 # 16 superframes per wave
+    (64, {0: 80, 3: 12, 5: 5, 8: 3}),                       # a superframe = one wave
+    (256, {0: 85, 1: 5, 4: 8, 6: 2}),                       # a superframe = the whole workgroup
+    (3, {0: 60, 1: 20, 3: 15, 6: 5}),                       # superframes straddle waves (85 per pass)
+    (1, {0: 70, 3: 20, 6: 10}),                             # 128 superframes per pass
+])
+def test_rs_error_mixes(V, O, torch_cuda, rsdims, weights):
+    """The locator-root search has three forms (closed form, a wavefront per column with the rest of a failed
+    superframe dropped, a column per lane); these mixes reach all of them and the hand-over between them."""
+    torch = torch_cuda
+    rng = np.random.default_rng(1000 + rsdims + len(weights))
+    nsf = max(24, 3072 // rsdims)
+    kinds = np.array(list(weights.keys())); pr = np.array(list(weights.values()), float); pr /= pr.sum()
+    p = np.empty((nsf, 120, rsdims), np.uint8)
+    for s_ in range(nsf):
+        for j in range(rsdims):
+            cw = O.rs_encode(rng.integers(0, 256, 110, dtype=np.uint8))
+            ne = int(rng.choice(kinds, p=pr))
+            pos = rng.choice(120, ne, replace=False)
+            cw[pos] ^= rng.integers(1, 256, ne, dtype=np.uint8)
+            p[s_, :, j] = cw
+    p = p.reshape(nsf, 120 * rsdims)
+    init = np.full((nsf, 110 * rsdims), 0xA5, np.uint8)
+    ret_ref, out_ref = O.rs_check_batch(p, rsdims, out_init=init)
+    d_p = torch.from_numpy(p).cuda()
+    d_out = torch.from_numpy(init.copy()).cuda()
+    d_ret = torch.full((nsf,), 12345, dtype=torch.int32, device="cuda")
+    V.rs_batch_dev(d_p, d_out, d_ret, rsdims, nsf)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_ret.cpu().numpy(), ret_ref)
+    assert np.array_equal(d_out.cpu().numpy(), out_ref)
+
+
 def test_rs_wide_superframe(V, O, torch_cuda):
     """more columns than a workgroup has lanes: chunked walk keeps the early-exit rule"""
     rsdims, nsf = 300, 3

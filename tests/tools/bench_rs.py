@@ -20,6 +20,8 @@ for s in range(base_n):
         if mode == "clean": ne = 0
         elif mode == "light": ne = int(rng.random() < 0.06)
         elif mode in ("le2", "le3", "le5"): ne = int(rng.integers(0, int(mode[2]) + 1))
+        elif mode == "rough":  # a poor channel: mostly clean, a few columns beyond two errors, rare failures
+            ne = int(rng.choice([0, 1, 2, 3, 4, 5, 6], p=[0.88, 0.06, 0.025, 0.015, 0.01, 0.007, 0.003]))
         else: ne = int(rng.choice([0, 0, 0, 0, 1, 2, 3, 5, 6]))
         pos = rng.choice(120, ne, replace=False); cw[pos] ^= rng.integers(1, 256, ne, dtype=np.uint8)
         p[s, :, j] = cw

@@ -25,8 +25,14 @@ constexpr int NROOTS = 10;   // viterbi.h:97
 constexpr int PADN = 135;    // rschecksf.cpp:45
 constexpr int NCW = 120, NMSG = 110;
 constexpr int RS_THREADS = 256;
-constexpr int ATO_ZERO = 512;   // index form of a zero coefficient where a lookup must give 0: ato[512..607] = 0
-constexpr int ATO_SIZE = 608;
+constexpr int ATO_ZERO = 512;   // index form of a zero coefficient where a lookup must give 0: ato[512..767] = 0
+constexpr int ATO_SIZE = 768;
+#ifndef COOP_MAX3
+#define COOP_MAX3 12   // most degree-3-or-more columns in a wave for the column-at-a-time search (dmax = 3 / dmax = 4, 5)
+#endif
+#ifndef COOP_MAX5
+#define COOP_MAX5 24
+#endif
 
 struct GfTables {
     uint8_t ato[ATO_SIZE];  // alpha_to[i % 255] for i < 512 (viterbi.h:101-105), zeros from ATO_ZERO on
@@ -113,11 +119,12 @@ constexpr StepTable make_step_table() {
 }
 __constant__ StepTable g_step = make_step_table();
 
-__device__ __forceinline__ uint32_t mod255(uint32_t x) { return (x * 0x1010102u) >> 24; }
+__device__ __forceinline__ uint32_t mod255(uint32_t x) { return (x * 0x1010102u) >> 24; }  // x < 65536
+__device__ __forceinline__ uint32_t mod510(uint32_t x) { return x < x - NN ? x : x - NN; }  // x < 510 (x - 255 wraps below 255)
 
 // Chien search over i = 1..255 (rschecksf.cpp:299-320) in the reference's own form - the logs b[j] advance by j, the sum
 // is over alpha_to[b[j]] - for the rare wave that holds a locator above degree 5 (never correctable, but its roots are
-// counted).  Roots go to the column's parity rows like chien_quad's.  Lanes with need == false find nothing.
+// counted).  Roots go to the column's parity rows like chien_wave's.  Lanes with need == false find nothing.
 __device__ __forceinline__ int chien_log(const uint32_t (&lam)[NROOTS + 1], bool need, int deg_lambda, uint8_t* col,
                                          uint32_t stride, const uint8_t* __restrict__ ato) {
     uint32_t b[NROOTS + 1], live[NROOTS + 1];
@@ -147,12 +154,12 @@ __device__ __forceinline__ int chien_log(const uint32_t (&lam)[NROOTS + 1], bool
     return count;
 }
 
-// The same search four positions per lookup, for locators of degree <= D <= 5 (the 255 dependent byte lookups per term of
-// the loop above kept the LDS busy for most of the error path: 0.63 ms of the 1.01 ms a batch with three-error
-// columns took).  adr[j] = 4 * lambda_j * alpha^(j*i0): one dword of the step table gives the term at i0+1..i0+4 and
-// the next address; the XOR of the terms' dwords evaluates the locator at four positions at once, a zero byte is a root.
-// Roots go to the column's parity rows (rows 110..119 are dead once the syndromes are known and are never output).
-// Lanes with need == false carry zero terms and find nothing.  Returns the number of roots in 1..255.
+// Chien search, four positions per lookup, every lane on its own column, for locators of degree <= D <= 5.
+// adr[j] = 4 * lambda_j * alpha^(j*i0): one dword of the step table gives the term at i0+1..i0+4 and the next address;
+// the XOR of the terms' dwords evaluates the locator at four positions at once, a zero byte is a root.
+// Roots go to the column's parity rows (rows 110..119 are dead once the syndromes are known and are never output; Forney
+// takes the set in any order).  Lanes with need == false carry zero terms and find nothing.  Returns the number of roots.
+// (The 255-step byte scan it replaces cost 0.63 ms of the 1.01 ms a batch with three-error columns took; this 0.11.)
 template <int D>
 __device__ __forceinline__ int chien_quad(const uint32_t (&lam)[NROOTS + 1], bool need, uint8_t* col, uint32_t stride,
                                           const uint8_t* __restrict__ ato, const uint32_t* __restrict__ step) {
@@ -181,7 +188,7 @@ __device__ __forceinline__ int chien_quad(const uint32_t (&lam)[NROOTS + 1], boo
             while (m) {
                 const uint32_t bit = (uint32_t)__ffs((int)m) - 1u;
                 m &= m - 1u;
-                col[(uint32_t)(NMSG + count) * stride] = (uint8_t)(32u * blk + 4u * (bit & 7u) + (bit >> 3) + 1u);  // ascending
+                col[(uint32_t)(NMSG + count) * stride] = (uint8_t)(32u * blk + 4u * (bit & 7u) + (bit >> 3) + 1u);
                 count++;
             }
         }
@@ -189,8 +196,72 @@ __device__ __forceinline__ int chien_quad(const uint32_t (&lam)[NROOTS + 1], boo
     return count;
 }
 
-// Everything after the syndromes: s[] = the ten syndromes in polynomial form, not all zero.
-// Codeword byte k is col[k * stride].  Returns root count or -1 when uncorrectable; patches in place.
+// The same search one column at a time with the whole wavefront on it: lane L evaluates the locator at the four
+// positions i = 4L+1 .. 4L+4, so 64 lanes cover 1..256 in one step (256 = position 1 again, masked).  Term j at those
+// positions is lambda_j * alpha^(4jL) * (alpha^j, alpha^2j, alpha^3j, alpha^4j): one byte of alpha_to at
+// log(lambda_j) + (4jL mod 255) - a lane-strided read, the log broadcast from the owning lane - and one dword of the
+// step table.  Cost is per column (about 1/23 of chien_quad<5>'s fixed cost), and the columns are taken in lane order =
+// column order within a superframe, which lets the reference's rule work for us: once a column of a superframe has
+// failed (here, or in `failed` = the lanes whose closed form already did), the later columns of that superframe are
+// never output and are dropped from the list (`dropped`: their lanes return 0 and patch nothing).  In a batch with
+// uncorrectable columns that is most of the work.  Must be called by all 64 lanes.
+template <int D>
+__device__ __forceinline__ void chien_wave(const uint32_t (&lam)[NROOTS + 1], bool need, bool failed, int deg_lambda,
+                                           uint32_t sfid, int& count, bool& dropped, uint8_t* cwbase, uint32_t coloff,
+                                           uint32_t stride, const uint8_t* __restrict__ ato,
+                                           const uint32_t* __restrict__ step) {
+    static_assert(D <= STEP_TERMS, "step table");
+    const uint32_t lane = __lane_id();
+    uint32_t e[D + 1], lgz[D + 1];
+#pragma unroll
+    for (int j = 1; j <= D; j++) {
+        e[j] = mod255(4u * (uint32_t)j * lane);
+        lgz[j] = lam[j] == (uint32_t)NN ? (uint32_t)ATO_ZERO : lam[j];  // a zero coefficient reads alpha_to's zero block
+    }
+    const uint32_t keep = lane == 63u ? 0x7FFFFFFFu : 0xFFFFFFFFu;  // position 256 = position 1 again
+    const uint64_t failm = __ballot(failed);
+    uint64_t work = __ballot(need) | failm;
+    uint64_t gone = 0;
+    while (work) {
+        const int owner = __builtin_ctzll(work);
+        work &= work - 1;
+        bool fail = true;
+        if (!((failm >> owner) & 1u)) {
+            uint32_t q = 0x01010101u;  // lambda_0 = 1 at each of the four positions
+#pragma unroll
+            for (int j = 1; j <= D; j++) {
+                const uint32_t c = ato[(uint32_t)__builtin_amdgcn_readlane(lgz[j], owner) + e[j]];  // <= 512 + 254
+                q ^= step[(j - 1) * 256 + c];
+            }
+            uint32_t z = ~(((q & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | q | 0x7F7F7F7Fu) & keep;  // 0x80 exactly where a byte is 0
+            uint8_t* ocol = cwbase + __builtin_amdgcn_readlane(coloff, owner);
+            uint32_t found = 0;
+            uint64_t hit;
+            while ((hit = __ballot(z != 0)) != 0) {  // a second trip only when a lane holds two roots
+                if (z) {
+                    const uint32_t below =
+                        __builtin_amdgcn_mbcnt_hi((uint32_t)(hit >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hit, 0u));
+                    const uint32_t k = ((uint32_t)__ffs((int)z) - 1u) >> 3;
+                    ocol[__umul24(NMSG + found + below, stride)] = (uint8_t)(4u * lane + k + 1u);
+                    z &= z - 1u;
+                }
+                found += (uint32_t)__popcll(hit);
+            }
+            if (lane == (uint32_t)owner) count = (int)found;
+            fail = (int)found != __builtin_amdgcn_readlane(deg_lambda, owner);
+        }
+        if (fail) {
+            const uint64_t later = __ballot(sfid == (uint32_t)__builtin_amdgcn_readlane(sfid, owner)) & ~((2ull << owner) - 1ull);
+            work &= ~later;
+            gone |= later;
+        }
+    }
+    dropped = (gone >> lane) & 1u;
+}
+
+// Everything after the syndromes, for the lanes with err set: s[] = their ten syndromes in polynomial form, not all
+// zero.  Codeword byte k of a lane is cwbase[coloff + k * stride].  Returns root count or -1 when uncorrectable (0 for
+// the other lanes); patches in place.  ALL 64 lanes of the wavefront must call it together (chien_wave).
 // Every small polynomial array is indexed with compile-time constants only (loops fully
 // unrolled, data-dependent bounds turned into predicates): dynamically indexed register arrays
 // cost a v_cndmask chain per access on this target and made the error path ~8x slower.
@@ -198,74 +269,87 @@ __device__ __forceinline__ int chien_quad(const uint32_t (&lam)[NROOTS + 1], boo
 // worst column of the wave; wave-uniform guards (__any, the wave's largest locator degree) skip the
 // terms that are zero in every lane - after a few single-symbol errors that is most of them.
 // qrow = byte 10 of the generator table's row 0: Q[x] is qrow[16 * x].
-__device__ int rs_correct(uint32_t (&s)[NROOTS], uint8_t* col, uint32_t stride, const uint8_t* __restrict__ ato,
-                          const uint8_t* __restrict__ iof, const uint8_t* __restrict__ qrow,
-                          const uint32_t* __restrict__ step) {
+__device__ int rs_correct(uint32_t (&s)[NROOTS], bool err, uint32_t sfid, uint8_t* cwbase, uint32_t coloff,
+                          uint32_t stride, const uint8_t* __restrict__ ato, const uint8_t* __restrict__ iof,
+                          const uint8_t* __restrict__ qrow, const uint32_t* __restrict__ step) {
+    uint8_t* const col = cwbase + coloff;
+    uint32_t lam[NROOTS + 1];
 #pragma unroll
-    for (int i = 0; i < NROOTS; i++) s[i] = iof[s[i]];  // index form (s[10] of the reference is never used)
-
-    // lambda / b: only entries 0..10 of the reference's 16-byte vectors are ever read
-    uint32_t lam[NROOTS + 1], b[NROOTS + 1];
-#pragma unroll
-    for (int i = 0; i <= NROOTS; i++) { lam[i] = 0; b[i] = NN; }
-    lam[0] = 1;
-    b[0] = 0;
-    int el = 0;
-    // Single-symbol shortcut.  One error e at position p gives S_i = e * alpha^(i*p): a geometric sequence, and then
-    // Berlekamp-Massey's answer is the unique connection polynomial 1 + (S_1/S_0) x (2L <= 10).  What the Viterbi decoder
-    // leaves behind is almost always that (a burst of a few bits lands in one or two different columns), so when EVERY
-    // erroneous column of the wave passes the test the ten BM iterations are skipped; anything else takes them.
-    bool geo = s[0] != NN && s[1] != NN;
-    const uint32_t lr = mod255(s[1] + NN - s[0]);  // log(S_1 / S_0); meaningless unless geo
-#pragma unroll
-    for (int i = 2; i < NROOTS; i++) geo = geo && s[i] == mod255(s[0] + (uint32_t)i * lr);  // a zero S_i (255) never matches
-    const bool shortcut = __all(geo);
-    if (shortcut) lam[1] = ato[lr];
-#pragma unroll
-    for (int r = 1; r <= NROOTS; r++) {  // Berlekamp-Massey (rschecksf.cpp:240-284)
-        if (shortcut) break;
-        uint32_t discr = 0;
-#pragma unroll
-        for (int i = 0; i < r; i++) {
-            const bool term = lam[i] != 0 && s[r - i - 1] != NN;
-            if (__any(term)) {
-                if (term) discr ^= ato[iof[lam[i]] + s[r - i - 1]];
-            }
-        }
-        discr = iof[discr];
-        const bool zero = discr == NN;
-        if (__any(!zero)) {
-            const bool grow = !zero && 2 * el <= r - 1;
-            uint32_t t[NROOTS + 1];
-            t[0] = lam[0];
-#pragma unroll
-            for (int i = 0; i < NROOTS; i++) {
-                t[i + 1] = lam[i + 1];
-                if (!zero && b[i] != NN) t[i + 1] ^= ato[discr + b[i]];
-            }
-            if (grow) el = r - el;
-            // b <- inv(discr) * lambda (grow) or x * b (otherwise: _mm_slli_si128(b,1), b[0] = 255)
-#pragma unroll
-            for (int i = NROOTS; i >= 0; i--) {
-                const uint32_t scaled = lam[i] == 0 ? (uint32_t)NN : mod255(iof[lam[i]] - discr + NN);
-                const uint32_t shifted = i ? b[i - 1] : (uint32_t)NN;
-                b[i] = grow ? scaled : shifted;
-            }
-#pragma unroll
-            for (int i = 0; i <= NROOTS; i++) lam[i] = zero ? lam[i] : t[i];
-        } else {  // zero discrepancy in every lane: lambda stays, b <- x * b
-#pragma unroll
-            for (int i = NROOTS; i > 0; i--) b[i] = b[i - 1];
-            b[0] = NN;
-        }
-    }
+    for (int i = 0; i <= NROOTS; i++) lam[i] = NN;
     int deg_lambda = 0;
+    if (err) {
 #pragma unroll
-    for (int i = 0; i <= NROOTS; i++) {
-        lam[i] = iof[lam[i]];
-        if (lam[i] != NN) deg_lambda = i;
+        for (int i = 0; i < NROOTS; i++) s[i] = iof[s[i]];  // index form (s[10] of the reference is never used)
+
+        // lambda / b: only entries 0..10 of the reference's 16-byte vectors are ever read.  lam[] is kept in index form
+        // (255 = zero coefficient) - every use but the XOR of the update wants the log - next to its polynomial form pl[].
+        // Before step r both polynomials have degree < r, which bounds every loop of the step at compile time.
+        uint32_t pl[NROOTS + 1], b[NROOTS + 1];
+#pragma unroll
+        for (int i = 0; i <= NROOTS; i++) { pl[i] = 0; b[i] = NN; }
+        pl[0] = 1;
+        lam[0] = 0;
+        b[0] = 0;
+        int el = 0;
+        // Single-symbol shortcut.  One error e at position p gives S_i = e * alpha^(i*p): a geometric sequence, and then
+        // Berlekamp-Massey's answer is the unique connection polynomial 1 + (S_1/S_0) x (2L <= 10).  What the Viterbi decoder
+        // leaves behind is almost always that (a burst of a few bits lands in one or two different columns), so when EVERY
+        // erroneous column of the wave passes the test the ten BM iterations are skipped; anything else takes them.
+        bool geo = s[0] != NN && s[1] != NN;
+        const uint32_t lr = mod510(s[1] + NN - s[0]);  // log(S_1 / S_0); meaningless unless geo
+        uint32_t expect = s[1];
+#pragma unroll
+        for (int i = 2; i < NROOTS; i++) {
+            expect = mod510(expect + lr);  // log S_0 + i * lr
+            geo = geo && s[i] == expect;   // a zero S_i (255) never matches
+        }
+        const bool shortcut = __all(geo);
+        if (shortcut) lam[1] = lr;
+#pragma unroll
+        for (int r = 1; r <= NROOTS; r++) {  // Berlekamp-Massey (rschecksf.cpp:240-284)
+            if (shortcut) break;
+            uint32_t discr = 0;
+#pragma unroll
+            for (int i = 0; i < r; i++) {
+                const bool term = lam[i] != NN && s[r - i - 1] != NN;
+                if (__any(term)) {
+                    if (term) discr ^= ato[lam[i] + s[r - i - 1]];
+                }
+            }
+            discr = iof[discr];
+            const bool zero = discr == NN;
+            if (__any(!zero)) {
+                const bool grow = !zero && 2 * el <= r - 1;
+                uint32_t t[NROOTS + 1];
+#pragma unroll
+                for (int i = 0; i < r; i++) {
+                    t[i + 1] = pl[i + 1];
+                    if (!zero && b[i] != NN) t[i + 1] ^= ato[discr + b[i]];
+                }
+                if (grow) el = r - el;
+                // b <- inv(discr) * lambda (grow) or x * b (otherwise: _mm_slli_si128(b,1), b[0] = 255)
+#pragma unroll
+                for (int i = r; i >= 0; i--) {
+                    const uint32_t scaled = lam[i] == NN ? (uint32_t)NN : mod510(lam[i] + NN - discr);
+                    const uint32_t shifted = i ? b[i - 1] : (uint32_t)NN;
+                    b[i] = grow ? scaled : shifted;
+                }
+#pragma unroll
+                for (int i = 1; i <= r; i++) {
+                    pl[i] = zero ? pl[i] : t[i];
+                    lam[i] = iof[pl[i]];
+                }
+            } else {  // zero discrepancy in every lane: lambda stays, b <- x * b
+#pragma unroll
+                for (int i = r; i > 0; i--) b[i] = b[i - 1];
+                b[0] = NN;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i <= NROOTS; i++)
+            if (lam[i] != NN) deg_lambda = i;
     }
-    int dmax = 0;  // largest locator degree in this wave (uniform)
+    int dmax = 0;  // largest locator degree in this wave (uniform; deg_lambda = 0 in the lanes without an error)
 #pragma unroll
     for (int d = 1; d <= NROOTS; d++)
         if (__any(deg_lambda >= d)) dmax = d;
@@ -302,18 +386,37 @@ __device__ int rs_correct(uint32_t (&s)[NROOTS], uint8_t* col, uint32_t stride, 
             count = 1;
         }
     }
+    bool dropped = false;
+#ifdef RS_DBG_NOCHIEN
+    if (deg_lambda >= 3) count = deg_lambda;
+    if (false) {
+#else
     if (dmax >= 3) {  // the scan, for the lanes of degree 3 and above
+#endif
         const bool need = deg_lambda >= 3;
-        const int found = dmax <= 3            ? chien_quad<3>(lam, need, col, stride, ato, step)
-                          : dmax <= STEP_TERMS ? chien_quad<STEP_TERMS>(lam, need, col, stride, ato, step)
-                                               : chien_log(lam, need, deg_lambda, col, stride, ato);
-        if (need) {
-            count = found;
+        if (dmax <= STEP_TERMS) {
+            // few such columns, or failures that end their superframes early: one step per column; a wave full of them:
+            // one column per lane (chien_quad's cost does not depend on how many lanes need it)
+            const int heavy = __popcll(__ballot(need));
+            if (heavy <= (dmax <= 3 ? COOP_MAX3 : COOP_MAX5)) {
+                const bool failed = err && !need && deg_lambda != count;
+                if (dmax <= 3) chien_wave<3>(lam, need, failed, deg_lambda, sfid, count, dropped, cwbase, coloff, stride, ato, step);
+                else chien_wave<STEP_TERMS>(lam, need, failed, deg_lambda, sfid, count, dropped, cwbase, coloff, stride, ato, step);
+            } else {
+                const int found = dmax <= 3 ? chien_quad<3>(lam, need, col, stride, ato, step)
+                                            : chien_quad<STEP_TERMS>(lam, need, col, stride, ato, step);
+                if (need) count = found;
+            }
+        } else if (need) {
+            count = chien_log(lam, need, deg_lambda, col, stride, ato);
+        }
+        if (need && !dropped) {
 #pragma unroll
             for (int k = 0; k < NROOTS; k++)
-                if (k < dmax && k < found) root[k] = col[(uint32_t)(NMSG + k) * stride];
+                if (k < dmax && k < count) root[k] = col[(uint32_t)(NMSG + k) * stride];
         }
     }
+    if (!err || dropped) return 0;
     if (deg_lambda != count) return -1;
 
     const int deg_omega = deg_lambda - 1;
@@ -353,38 +456,42 @@ __device__ int rs_correct(uint32_t (&s)[NROOTS], uint8_t* col, uint32_t stride, 
     return count;
 }
 
-// Transposed-LDS front end (codeword byte k at col[k * RS_THREADS]): Horner syndromes (rschecksf.cpp:212-219)
-// with per-root product tables (mulp[i][x] = x * alpha^i: one LDS byte per multiply-add).
-__device__ int decode_rs(uint8_t* col, const uint8_t* __restrict__ ato, const uint8_t* __restrict__ iof,
-                         const uint8_t* __restrict__ mulp, const uint8_t* __restrict__ qrow,
-                         const uint32_t* __restrict__ step) {
+// Transposed-LDS front end (codeword byte k at cw[tid + k * RS_THREADS]): Horner syndromes (rschecksf.cpp:212-219)
+// with per-root product tables (mulp[i][x] = x * alpha^i: one LDS byte per multiply-add).  Called by all lanes.
+__device__ int decode_rs(bool active, uint32_t sfid, uint8_t* cw, uint32_t tid, const uint8_t* __restrict__ ato,
+                         const uint8_t* __restrict__ iof, const uint8_t* __restrict__ mulp,
+                         const uint8_t* __restrict__ qrow, const uint32_t* __restrict__ step) {
     uint32_t s[NROOTS];
-    const uint32_t d0 = col[0];
-#pragma unroll
-    for (int i = 0; i < NROOTS; i++) s[i] = d0;
-    for (int j = 1; j < NCW; j++) {
-        const uint32_t d = col[j * RS_THREADS];
-        s[0] ^= d;
-#pragma unroll
-        for (int i = 1; i < NROOTS; i++) s[i] = d ^ mulp[i * 256 + s[i]];
-    }
     uint32_t syn = 0;
+    if (active) {
+        const uint8_t* col = cw + tid;
+        const uint32_t d0 = col[0];
 #pragma unroll
-    for (int i = 0; i < NROOTS; i++) syn |= s[i];
-    if (!syn) return 0;
-    return rs_correct(s, col, RS_THREADS, ato, iof, qrow, step);
+        for (int i = 0; i < NROOTS; i++) s[i] = d0;
+        for (int j = 1; j < NCW; j++) {
+            const uint32_t d = col[j * RS_THREADS];
+            s[0] ^= d;
+#pragma unroll
+            for (int i = 1; i < NROOTS; i++) s[i] = d ^ mulp[i * 256 + s[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < NROOTS; i++) syn |= s[i];
+    }
+    if (!__any(syn != 0)) return 0;
+    return rs_correct(s, syn != 0, sfid, cw, tid, RS_THREADS, ato, iof, qrow, step);
 }
 
 struct __attribute__((aligned(16))) G3 {
     uint32_t x, y, z;
 };
-// Natural-layout front end (codeword byte k at col[k * stride]): remainder modulo g(x) by LFSR,
-// r <- r*x + d_k - r_9*(x^10 + g(x)): one 16-byte lookup of the feedback byte per data byte.
-__device__ int decode_rs_lfsr(uint8_t* col, uint32_t stride, const uint8_t* __restrict__ ato,
-                              const uint8_t* __restrict__ iof, const uint32_t* __restrict__ gtab,
-                              const uint32_t* __restrict__ step) {
+// Natural-layout front end (codeword byte k at cwbase[coloff + k * stride]): remainder modulo g(x) by LFSR,
+// r <- r*x + d_k - r_9*(x^10 + g(x)): one 16-byte lookup of the feedback byte per data byte.  Called by all lanes; the
+// ones without a column (active == false) walk a valid one and drop the result.
+__device__ int decode_rs_lfsr(bool active, uint32_t sfid, uint8_t* cwbase, uint32_t coloff, uint32_t stride,
+                              const uint8_t* __restrict__ ato, const uint8_t* __restrict__ iof,
+                              const uint32_t* __restrict__ gtab, const uint32_t* __restrict__ step) {
     uint32_t r0 = 0, r1 = 0, r2 = 0;  // coefficient r_j = byte j of the 80-bit register (r2 above bit 15: junk)
-    const uint8_t* q = col;
+    const uint8_t* q = cwbase + coloff;
 #pragma unroll 8
     for (int k = 0; k < NCW; k++, q += stride) {
         const uint32_t d = *q;
@@ -395,27 +502,30 @@ __device__ int decode_rs_lfsr(uint8_t* col, uint32_t stride, const uint8_t* __re
         r0 = ((r0 << 8) | d) ^ t.x;
     }
     r2 &= 0xFFFFu;
-    if ((r0 | r1 | r2) == 0) return 0;
+    const bool err = active && (r0 | r1 | r2) != 0;
+    if (!__any(err)) return 0;
     // syndromes S_i = r(alpha^i) = sum_j r_j alpha^(i*j) (= the reference's Horner sums over the whole codeword), through
     // the logs of the ten coefficients: independent lookups at ato[log r_j + i*j], a zero coefficient reads the zero block
-    uint32_t lg[NROOTS];
     uint32_t s[NROOTS];
-    s[0] = 0;
+    if (err) {
+        uint32_t lg[NROOTS];
+        s[0] = 0;
 #pragma unroll
-    for (int j = 0; j < NROOTS; j++) {
-        const uint32_t c = ((j < 4 ? r0 : j < 8 ? r1 : r2) >> (8 * (j & 3))) & 0xFFu;
-        s[0] ^= c;
-        lg[j] = c ? (uint32_t)iof[c] : (uint32_t)ATO_ZERO;
+        for (int j = 0; j < NROOTS; j++) {
+            const uint32_t c = ((j < 4 ? r0 : j < 8 ? r1 : r2) >> (8 * (j & 3))) & 0xFFu;
+            s[0] ^= c;
+            lg[j] = c ? (uint32_t)iof[c] : (uint32_t)ATO_ZERO;
+        }
+#pragma unroll
+        for (int i = 1; i < NROOTS; i++) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int j = 0; j < NROOTS; j++) v ^= ato[lg[j] + (uint32_t)(i * j)];  // <= 512 + 81
+            s[i] = v;
+            if (i % 3 == 0) __builtin_amdgcn_sched_barrier(0);  // 30 lookups in flight are plenty; all 90 cost spills
+        }
     }
-#pragma unroll
-    for (int i = 1; i < NROOTS; i++) {
-        uint32_t v = 0;
-#pragma unroll
-        for (int j = 0; j < NROOTS; j++) v ^= ato[lg[j] + (uint32_t)(i * j)];  // <= 512 + 81
-        s[i] = v;
-        if (i % 3 == 0) __builtin_amdgcn_sched_barrier(0);  // 30 lookups in flight are plenty; all 90 cost spills
-    }
-    return rs_correct(s, col, stride, ato, iof, reinterpret_cast<const uint8_t*>(gtab) + 10, step);
+    return rs_correct(s, err, sfid, cwbase, coloff, stride, ato, iof, reinterpret_cast<const uint8_t*>(gtab) + 10, step);
 }
 
 // General form (used for rsdims > 256).  Workgroup = 256 lanes.  For rsdims <= 256 it takes spb = 256/rsdims
@@ -460,13 +570,12 @@ __global__ __launch_bounds__(RS_THREADS) void rs_kernel_wide(const uint8_t* __re
             __syncthreads();
             const uint32_t colidx = rsdims <= RS_THREADS ? tid - lsf * rsdims : ch * RS_THREADS + tid;
             const bool active = lsf < spb && sf < nsf && colidx < rsdims && !s_fail[lsfc];
-            int res = 0;
             if (active) {
                 const uint8_t* src = p + (size_t)sf * in_sz + colidx;
                 for (int k = 0; k < NCW; k++) cw[k * RS_THREADS + tid] = src[(size_t)k * rsdims];
-                res = decode_rs(&cw[tid], ato, iof, mulp, qrow, step);
-                if (res < 0) atomicMin(&s_minfail[lsf], (int)colidx);
             }
+            const int res = decode_rs(active, lsf, cw, tid, ato, iof, mulp, qrow, step);  // all lanes
+            if (res < 0) atomicMin(&s_minfail[lsf], (int)colidx);
             __syncthreads();
             const int mf = s_minfail[lsfc];
             if (active && (int)colidx < mf) {  // columns before the first failure are written
@@ -502,7 +611,7 @@ __device__ __forceinline__ void copy_linear(uint8_t* dst, const uint8_t* src, ui
 constexpr uint32_t RS_MAX_SPB = 128;  // superframes per pass of rs_kernel: the generator table has 2 x 128 spare words
 
 // rsdims <= 256: spb = min(256/rsdims, 128) superframes per pass, natural layout in LDS (see the header comment).
-// LDS: 30720 (codewords) + 4096 (generator rows, Q, the per-superframe words) + 5120 (Chien steps) + 608 + 256 = 40800 B,
+// LDS: 30720 (codewords) + 4096 (generator rows, Q, the per-superframe words) + 5120 (Chien steps) + 768 + 256 = 40960 B,
 // which is what lets four workgroups share a CU (second launch bound: 4 waves per SIMD); the three-workgroup build
 // that kept every table separate was 6 % slower on clean data (profiles/r02_ab_rs_chien.txt).
 __global__ __launch_bounds__(RS_THREADS, 4) void rs_kernel(const uint8_t* __restrict__ p, uint8_t* __restrict__ out,
@@ -566,11 +675,8 @@ __global__ __launch_bounds__(RS_THREADS, 4) void rs_kernel(const uint8_t* __rest
         }
         __syncthreads();
         const bool active = lsf < nloc;
-        int res = 0;
-        if (active) {
-            res = decode_rs_lfsr(cw + lsf * in_sz + colidx, rsdims, ato, iof, gtab, step);
-            if (res < 0) atomicMin(&s_minfail[4 * lsf], (int)colidx);
-        }
+        const int res = decode_rs_lfsr(active, lsf, cw, active ? lsf * in_sz + colidx : 0u, rsdims, ato, iof, gtab, step);  // all lanes
+        if (res < 0) atomicMin(&s_minfail[4 * lsf], (int)colidx);
         __syncthreads();
         uint8_t* dst0 = out + (size_t)sf0 * out_sz;
         // superframes without a failure: their first 110 rows go out as one linear block each
@@ -579,14 +685,19 @@ __global__ __launch_bounds__(RS_THREADS, 4) void rs_kernel(const uint8_t* __rest
             for (uint32_t c = tid; c < nloc * wps; c += RS_THREADS) {
                 const uint32_t l = c / wps, o = c - l * wps;
                 if (s_minfail[4 * l] == NOFAIL)
-                    reinterpret_cast<uint32_t*>(dst0 + (size_t)l * out_sz)[o] =
+                    reinterpret_cast<uint32_t*>(dst0 + l * out_sz)[o] =
                         reinterpret_cast<const uint32_t*>(cw + l * in_sz)[o];
             }
             if (active) {
                 const int mf = s_minfail[4 * lsf];
+#ifdef RS_DBG_NOPARTIAL
+                if (false) {
+#else
                 if (mf != NOFAIL && (int)colidx < mf) {  // columns before the first failure are written
-                    uint8_t* dst = dst0 + (size_t)lsf * out_sz + colidx;
+#endif
+                    uint8_t* dst = dst0 + (lsf * out_sz + colidx);  // < 110 * 256
                     const uint8_t* src = cw + lsf * in_sz + colidx;
+#pragma clang loop vectorize(disable) interleave(disable)
                     for (int k = 0; k < NMSG; k++) dst[(size_t)k * rsdims] = src[k * rsdims];
                 }
                 if ((int)colidx < mf) atomicAdd(&s_sum[4 * lsf], res);
@@ -594,8 +705,9 @@ __global__ __launch_bounds__(RS_THREADS, 4) void rs_kernel(const uint8_t* __rest
         } else if (active) {
             const int mf = s_minfail[4 * lsf];
             if ((int)colidx < mf) {
-                uint8_t* dst = dst0 + (size_t)lsf * out_sz + colidx;
+                uint8_t* dst = dst0 + (lsf * out_sz + colidx);  // < 110 * 256
                 const uint8_t* src = cw + lsf * in_sz + colidx;
+#pragma clang loop vectorize(disable) interleave(disable)
                 for (int k = 0; k < NMSG; k++) dst[(size_t)k * rsdims] = src[k * rsdims];
                 atomicAdd(&s_sum[4 * lsf], res);
             }

@@ -387,12 +387,7 @@ __device__ int rs_correct(uint32_t (&s)[NROOTS], bool err, uint32_t sfid, uint8_
         }
     }
     bool dropped = false;
-#ifdef RS_DBG_NOCHIEN
-    if (deg_lambda >= 3) count = deg_lambda;
-    if (false) {
-#else
     if (dmax >= 3) {  // the scan, for the lanes of degree 3 and above
-#endif
         const bool need = deg_lambda >= 3;
         if (dmax <= STEP_TERMS) {
             // few such columns, or failures that end their superframes early: one step per column; a wave full of them:
@@ -597,7 +592,9 @@ __global__ __launch_bounds__(RS_THREADS) void rs_kernel_wide(const uint8_t* __re
 template <typename V>
 __device__ __forceinline__ void copy_vec(uint8_t* dst, const uint8_t* src, uint32_t n, uint32_t tid) {
     const uint32_t nv = n / (uint32_t)sizeof(V);
+#pragma clang loop vectorize(disable) interleave(disable)
     for (uint32_t i = tid; i < nv; i += RS_THREADS) reinterpret_cast<V*>(dst)[i] = reinterpret_cast<const V*>(src)[i];
+#pragma clang loop vectorize(disable) interleave(disable)
     for (uint32_t i = nv * (uint32_t)sizeof(V) + tid; i < n; i += RS_THREADS) dst[i] = src[i];
 }
 __device__ __forceinline__ void copy_linear(uint8_t* dst, const uint8_t* src, uint32_t n, uint32_t tid) {
@@ -606,6 +603,24 @@ __device__ __forceinline__ void copy_linear(uint8_t* dst, const uint8_t* src, ui
     else if ((a & 7u) == 0) copy_vec<uint2>(dst, src, n, tid);
     else if ((a & 3u) == 0) copy_vec<uint32_t>(dst, src, n, tid);
     else copy_vec<uint8_t>(dst, src, n, tid);
+}
+
+// Output of the superframes without a failure: their first 110 rows are one linear block each (out_sz bytes of the in_sz).
+// (l, o) = superframe and piece (of sizeof(V) bytes) of this thread, stepped RS_THREADS pieces at a time without a division.
+template <typename V>
+__device__ __forceinline__ void copy_out(uint8_t* dst0, const uint8_t* cw, const int* s_minfail, uint32_t nloc,
+                                         uint32_t in_sz, uint32_t out_sz, uint32_t tid) {
+    const uint32_t wps = out_sz / (uint32_t)sizeof(V);
+    uint32_t l = tid / wps, o = tid - l * wps;
+    while (l < nloc) {
+        if (s_minfail[4 * l] == 0x7FFFFFFF)
+            reinterpret_cast<V*>(dst0 + l * out_sz)[o] = reinterpret_cast<const V*>(cw + l * in_sz)[o];
+        o += RS_THREADS;
+        while (o >= wps) {
+            o -= wps;
+            l++;
+        }
+    }
 }
 
 constexpr uint32_t RS_MAX_SPB = 128;  // superframes per pass of rs_kernel: the generator table has 2 x 128 spare words
@@ -681,20 +696,16 @@ __global__ __launch_bounds__(RS_THREADS, 4) void rs_kernel(const uint8_t* __rest
         uint8_t* dst0 = out + (size_t)sf0 * out_sz;
         // superframes without a failure: their first 110 rows go out as one linear block each
         if ((out_sz & 3u) == 0 && (reinterpret_cast<uintptr_t>(dst0) & 3u) == 0) {
-            const uint32_t wps = out_sz >> 2;  // dwords per superframe; in_sz is a multiple of 8
-            for (uint32_t c = tid; c < nloc * wps; c += RS_THREADS) {
-                const uint32_t l = c / wps, o = c - l * wps;
-                if (s_minfail[4 * l] == NOFAIL)
-                    reinterpret_cast<uint32_t*>(dst0 + l * out_sz)[o] =
-                        reinterpret_cast<const uint32_t*>(cw + l * in_sz)[o];
-            }
+            // 16-byte pieces when the block sizes and the destination allow it (in_sz is a multiple of 8, both are of 16
+            // when rsdims is a multiple of 8), else dwords (the quotient c / wps in every trip of the plain loop was a
+            // quarter of the clean path's instructions)
+            if ((out_sz & 15u) == 0 && (in_sz & 15u) == 0 && (reinterpret_cast<uintptr_t>(dst0) & 15u) == 0)
+                copy_out<uint4>(dst0, cw, s_minfail, nloc, in_sz, out_sz, tid);
+            else
+                copy_out<uint32_t>(dst0, cw, s_minfail, nloc, in_sz, out_sz, tid);
             if (active) {
                 const int mf = s_minfail[4 * lsf];
-#ifdef RS_DBG_NOPARTIAL
-                if (false) {
-#else
                 if (mf != NOFAIL && (int)colidx < mf) {  // columns before the first failure are written
-#endif
                     uint8_t* dst = dst0 + (lsf * out_sz + colidx);  // < 110 * 256
                     const uint8_t* src = cw + lsf * in_sz + colidx;
 #pragma clang loop vectorize(disable) interleave(disable)

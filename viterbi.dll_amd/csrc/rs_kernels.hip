@@ -71,14 +71,17 @@ constexpr QuadTable make_quad_table() {
     return Q;
 }
 
-// G[x] = (x*g_0, ..., x*g_9) packed little-endian into 16 bytes, g(x) = prod_{i=0..9}(x + alpha^i)
-// (monic, degree 10): the feedback table of the remainder LFSR.  The six spare bytes of a row are used too (LDS is what
-// limits the kernel to four workgroups per CU): byte 10 = Q[x] (the LFSR ignores the upper half of dword 2), dword 3 of
-// rows 0..127 / 128..255 = the per-superframe first-failure / correction-count words of rs_kernel.
-struct GenTable {
-    uint32_t w[256 * 4];
+// Feedback table of the remainder LFSR.  Row(x) = (x*g_0, ..., x*g_9) in 16 bytes (g_0..g_7, four empty, g_8, g_9, two empty),
+// g(x) = prod_{i=0..9}(x + alpha^i) (monic, degree 10).  The row is linear in x over GF(2), so it is kept as TWO
+// 16-row tables, Row(x) = LO[x & 15] ^ HI[x >> 4]: 16 rows of 16 bytes are 256 B = one row per group of four LDS
+// banks, so a lookup never has a bank conflict - lanes with the same nibble read the same row (broadcast), lanes with
+// different nibbles different banks.  One 256-row table needs one lookup per step instead of two, but 64 random rows
+// cost it ~3x the conflict-free cycles: 0.27 ms per 131072 superframes against 0.18 ms with conflict-free rows
+// (measured with a fake index, profiles/r02_ab_rs_chien.txt), and that loop is LDS-bound.
+struct NibTable {
+    uint32_t w[2 * 16 * 4];  // LO rows, then HI rows
 };
-constexpr GenTable make_gen_table() {
+constexpr NibTable make_nib_table() {
     const GfTables t = make_tables();
     uint8_t g[NROOTS + 1] = {1};
     int deg = 0;
@@ -92,17 +95,19 @@ constexpr GenTable make_gen_table() {
         deg++;
         for (int j = 0; j <= deg; j++) g[j] = ng[j];
     }
-    GenTable G{};
-    for (int x = 1; x < 256; x++)
-        for (int j = 0; j < NROOTS; j++) {
-            const uint32_t prod = g[j] ? t.ato[t.iof[x] + t.iof[g[j]]] : 0u;
-            G.w[x * 4 + j / 4] |= prod << (8 * (j % 4));
+    NibTable G{};
+    for (int half = 0; half < 2; half++)
+        for (int n = 1; n < 16; n++) {
+            const int x = half ? n << 4 : n;
+            for (int j = 0; j < NROOTS; j++) {
+                const uint32_t prod = g[j] ? t.ato[t.iof[x] + t.iof[g[j]]] : 0u;
+                G.w[(half * 16 + n) * 4 + (j < 8 ? j / 4 : 3)] |= prod << (8 * (j % 4));  // g_8, g_9 in dword 3
+            }
         }
-    const QuadTable Q = make_quad_table();
-    for (int x = 0; x < 256; x++) G.w[x * 4 + 2] |= (uint32_t)Q.q[x] << 16;
     return G;
 }
-__constant__ GenTable g_gen = make_gen_table();
+__constant__ NibTable g_nib = make_nib_table();
+__constant__ QuadTable g_quad = make_quad_table();
 
 // Four Chien steps per lookup: W[j-1][c] = (c*a^j, c*a^2j, c*a^3j, c*a^4j) packed little-endian, j = 1..5 (a = alpha).
 constexpr int STEP_TERMS = 5;
@@ -119,6 +124,9 @@ constexpr StepTable make_step_table() {
 }
 __constant__ StepTable g_step = make_step_table();
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define LDS __attribute__((address_space(3)))
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 __device__ __forceinline__ uint32_t mod255(uint32_t x) { return (x * 0x1010102u) >> 24; }  // x < 65536
 __device__ __forceinline__ uint32_t mod510(uint32_t x) { return x < x - NN ? x : x - NN; }  // x < 510 (x - 255 wraps below 255)
 
@@ -268,10 +276,9 @@ __device__ __forceinline__ void chien_wave(const uint32_t (&lam)[NROOTS + 1], bo
 // A wavefront runs this path as soon as ONE of its 64 columns has an error, so its cost is set by the
 // worst column of the wave; wave-uniform guards (__any, the wave's largest locator degree) skip the
 // terms that are zero in every lane - after a few single-symbol errors that is most of them.
-// qrow = byte 10 of the generator table's row 0: Q[x] is qrow[16 * x].
 __device__ int rs_correct(uint32_t (&s)[NROOTS], bool err, uint32_t sfid, uint8_t* cwbase, uint32_t coloff,
                           uint32_t stride, const uint8_t* __restrict__ ato, const uint8_t* __restrict__ iof,
-                          const uint8_t* __restrict__ qrow, const uint32_t* __restrict__ step) {
+                          const uint8_t* __restrict__ qsol, const uint32_t* __restrict__ step) {
     uint8_t* const col = cwbase + coloff;
     uint32_t lam[NROOTS + 1];
 #pragma unroll
@@ -371,7 +378,7 @@ __device__ int rs_correct(uint32_t (&s)[NROOTS], bool err, uint32_t sfid, uint8_
         count = 1;
     } else if (dmax >= 2 && deg_lambda == 2) {
         if (lam[1] != NN) {
-            const uint32_t y0 = qrow[16u * ato[mod255(lam[2] + 2u * (NN - lam[1]))]];
+            const uint32_t y0 = qsol[ato[mod255(lam[2] + 2u * (NN - lam[1]))]];
             if (y0) {
                 const uint32_t scale = lam[1] + NN - lam[2];  // log(l1 / l2) + 255
                 uint32_t r0 = mod255(scale + iof[y0]), r1 = mod255(scale + iof[y0 ^ 1u]);
@@ -455,7 +462,7 @@ __device__ int rs_correct(uint32_t (&s)[NROOTS], bool err, uint32_t sfid, uint8_
 // with per-root product tables (mulp[i][x] = x * alpha^i: one LDS byte per multiply-add).  Called by all lanes.
 __device__ int decode_rs(bool active, uint32_t sfid, uint8_t* cw, uint32_t tid, const uint8_t* __restrict__ ato,
                          const uint8_t* __restrict__ iof, const uint8_t* __restrict__ mulp,
-                         const uint8_t* __restrict__ qrow, const uint32_t* __restrict__ step) {
+                         const uint8_t* __restrict__ qsol, const uint32_t* __restrict__ step) {
     uint32_t s[NROOTS];
     uint32_t syn = 0;
     if (active) {
@@ -473,28 +480,35 @@ __device__ int decode_rs(bool active, uint32_t sfid, uint8_t* cw, uint32_t tid, 
         for (int i = 0; i < NROOTS; i++) syn |= s[i];
     }
     if (!__any(syn != 0)) return 0;
-    return rs_correct(s, syn != 0, sfid, cw, tid, RS_THREADS, ato, iof, qrow, step);
+    return rs_correct(s, syn != 0, sfid, cw, tid, RS_THREADS, ato, iof, qsol, step);
 }
 
-struct __attribute__((aligned(16))) G3 {
-    uint32_t x, y, z;
-};
 // Natural-layout front end (codeword byte k at cwbase[coloff + k * stride]): remainder modulo g(x) by LFSR,
-// r <- r*x + d_k - r_9*(x^10 + g(x)): one 16-byte lookup of the feedback byte per data byte.  Called by all lanes; the
-// ones without a column (active == false) walk a valid one and drop the result.
+// r <- r*x + d_k - r_9*(x^10 + g(x)): two conflict-free 16-byte lookups (low and high nibble of the feedback byte,
+// see NibTable) per data byte.  Called by all lanes; the ones without a column (active == false) walk a valid one
+// and drop the result.
 __device__ int decode_rs_lfsr(bool active, uint32_t sfid, uint8_t* cwbase, uint32_t coloff, uint32_t stride,
                               const uint8_t* __restrict__ ato, const uint8_t* __restrict__ iof,
-                              const uint32_t* __restrict__ gtab, const uint32_t* __restrict__ step) {
+                              const uint8_t* __restrict__ qsol, const uint32_t* __restrict__ gnib,
+                              const uint32_t* __restrict__ step) {
     uint32_t r0 = 0, r1 = 0, r2 = 0;  // coefficient r_j = byte j of the 80-bit register (r2 above bit 15: junk)
     const uint8_t* q = cwbase + coloff;
+    const uint32_t nibbase = (uint32_t)(uintptr_t)(const LDS uint32_t*)gnib;  // LDS byte address
 #pragma unroll 8
     for (int k = 0; k < NCW; k++, q += stride) {
         const uint32_t d = *q;
-        const uint32_t f = (r2 >> 8) & 0xFFu;  // r_9
-        const G3 t = *reinterpret_cast<const G3*>(gtab + f * 4u);  // ds_read_b96: 10 of the 12 bytes are payload
-        r2 = __builtin_amdgcn_alignbit(r2, r1, 24) ^ t.z;
-        r1 = __builtin_amdgcn_alignbit(r1, r0, 24) ^ t.y;
-        r0 = ((r0 << 8) | d) ^ t.x;
+        const uint32_t f4 = r2 >> 4;  // bits 4..11 = r_9
+        // g_8, g_9 sit in the LAST dword of a row (the third is empty) so that the access stays ONE ds_read_b128
+        // (4 LDS cycles per wave): with the payload in the first 12 bytes the compiler narrows it to ds_read_b96,
+        // which takes 8 (measured: 0.36 ms against 0.20 per 131072 superframes of RSDims 24)
+        const u32x4 lo = *reinterpret_cast<const LDS u32x4*>(nibbase + (f4 & 0xF0u));
+        const u32x4 hi = *reinterpret_cast<const LDS u32x4*>(nibbase + 256u + ((f4 >> 4) & 0xF0u));
+        r2 = xor3(__builtin_amdgcn_alignbit(r2, r1, 24), lo.w, hi.w);
+        r1 = xor3(__builtin_amdgcn_alignbit(r1, r0, 24), lo.y, hi.y);
+        r0 = xor3((r0 << 8) | d, lo.x, hi.x);
+        // keep the empty dwords' registers allocated until the rows have arrived: reused for the next address they
+        // would put a wait for the lookup in front of its computation
+        asm volatile("" ::"v"(lo.z), "v"(hi.z));
     }
     r2 &= 0xFFFFu;
     const bool err = active && (r0 | r1 | r2) != 0;
@@ -520,7 +534,7 @@ __device__ int decode_rs_lfsr(bool active, uint32_t sfid, uint8_t* cwbase, uint3
             if (i % 3 == 0) __builtin_amdgcn_sched_barrier(0);  // 30 lookups in flight are plenty; all 90 cost spills
         }
     }
-    return rs_correct(s, err, sfid, cwbase, coloff, stride, ato, iof, reinterpret_cast<const uint8_t*>(gtab) + 10, step);
+    return rs_correct(s, err, sfid, cwbase, coloff, stride, ato, iof, qsol, step);
 }
 
 // General form (used for rsdims > 256).  Workgroup = 256 lanes.  For rsdims <= 256 it takes spb = 256/rsdims
@@ -533,7 +547,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_kernel_wide(const uint8_t* __re
     __shared__ uint8_t ato[ATO_SIZE];
     __shared__ uint8_t iof[256];
     __shared__ uint8_t mulp[(NROOTS + 1) * 256];  // mulp[i][x] = x * alpha^i, i = 0..10
-    __shared__ uint8_t qrow[256 * 16];            // Q[x] at 16 * x, as in rs_kernel's generator table
+    __shared__ uint8_t qsol[256];
     __shared__ uint32_t step[STEP_TERMS * 256];
     __shared__ int s_minfail[RS_THREADS];
     __shared__ int s_sum[RS_THREADS];
@@ -541,7 +555,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_kernel_wide(const uint8_t* __re
     const int tid = threadIdx.x;
     for (int i = tid; i < ATO_SIZE; i += RS_THREADS) ato[i] = g_gf.ato[i];
     iof[tid] = g_gf.iof[tid];
-    qrow[16 * tid] = (uint8_t)(g_gen.w[tid * 4 + 2] >> 16);
+    qsol[tid] = g_quad.q[tid];
     for (int i = 0; i <= NROOTS; i++) mulp[i * 256 + tid] = tid ? g_gf.ato[g_gf.iof[tid] + i] : 0;
     for (int i = tid; i < STEP_TERMS * 256; i += RS_THREADS) step[i] = g_step.w[i];
     __syncthreads();
@@ -569,7 +583,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_kernel_wide(const uint8_t* __re
                 const uint8_t* src = p + (size_t)sf * in_sz + colidx;
                 for (int k = 0; k < NCW; k++) cw[k * RS_THREADS + tid] = src[(size_t)k * rsdims];
             }
-            const int res = decode_rs(active, lsf, cw, tid, ato, iof, mulp, qrow, step);  // all lanes
+            const int res = decode_rs(active, lsf, cw, tid, ato, iof, mulp, qsol, step);  // all lanes
             if (res < 0) atomicMin(&s_minfail[lsf], (int)colidx);
             __syncthreads();
             const int mf = s_minfail[lsfc];
@@ -597,7 +611,8 @@ __device__ __forceinline__ void copy_vec(uint8_t* dst, const uint8_t* src, uint3
 #pragma clang loop vectorize(disable) interleave(disable)
     for (uint32_t i = nv * (uint32_t)sizeof(V) + tid; i < n; i += RS_THREADS) dst[i] = src[i];
 }
-__device__ __forceinline__ void copy_linear(uint8_t* dst, const uint8_t* src, uint32_t n, uint32_t tid) {
+// (not inlined: the fall-back for an input pointer that is not 8-byte aligned should cost the main loop no registers)
+__device__ __attribute__((noinline)) void copy_linear(uint8_t* dst, const uint8_t* src, uint32_t n, uint32_t tid) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src);
     if ((a & 15u) == 0) copy_vec<uint4>(dst, src, n, tid);
     else if ((a & 7u) == 0) copy_vec<uint2>(dst, src, n, tid);
@@ -613,7 +628,7 @@ __device__ __forceinline__ void copy_out(uint8_t* dst0, const uint8_t* cw, const
     const uint32_t wps = out_sz / (uint32_t)sizeof(V);
     uint32_t l = tid / wps, o = tid - l * wps;
     while (l < nloc) {
-        if (s_minfail[4 * l] == 0x7FFFFFFF)
+        if (s_minfail[l] == 0x7FFFFFFF)
             reinterpret_cast<V*>(dst0 + l * out_sz)[o] = reinterpret_cast<const V*>(cw + l * in_sz)[o];
         o += RS_THREADS;
         while (o >= wps) {
@@ -623,30 +638,30 @@ __device__ __forceinline__ void copy_out(uint8_t* dst0, const uint8_t* cw, const
     }
 }
 
-constexpr uint32_t RS_MAX_SPB = 128;  // superframes per pass of rs_kernel: the generator table has 2 x 128 spare words
-
-// rsdims <= 256: spb = min(256/rsdims, 128) superframes per pass, natural layout in LDS (see the header comment).
-// LDS: 30720 (codewords) + 4096 (generator rows, Q, the per-superframe words) + 5120 (Chien steps) + 768 + 256 = 40960 B,
-// which is what lets four workgroups share a CU (second launch bound: 4 waves per SIMD); the three-workgroup build
-// that kept every table separate was 6 % slower on clean data (profiles/r02_ab_rs_chien.txt).
+// rsdims <= 256: spb = 256/rsdims superframes per pass, natural layout in LDS (see the header comment).
+// LDS: 30720 (codewords) + 5120 (Chien steps) + 512 (LFSR nibble rows) + 768 + 256 + 256 + 2048 = 39680 B: four workgroups
+// share a CU (second launch bound: 4 waves per SIMD); a three-workgroup build was 6 % slower on clean data
+// (profiles/r02_ab_rs_chien.txt).
 __global__ __launch_bounds__(RS_THREADS, 4) void rs_kernel(const uint8_t* __restrict__ p, uint8_t* __restrict__ out,
                                                         int32_t* __restrict__ ret, uint32_t rsdims,
                                                         long long nsf, int host_polls_ret) {
     __shared__ __attribute__((aligned(16))) uint8_t cw[NCW * RS_THREADS];  // [superframe][row][column]
-    __shared__ __attribute__((aligned(16))) uint32_t gtab[256 * 4];
+    __shared__ __attribute__((aligned(256))) uint32_t gnib[2 * 16 * 4];
     __shared__ uint32_t step[STEP_TERMS * 256];
     __shared__ uint8_t ato[ATO_SIZE];
     __shared__ uint8_t iof[256];
+    __shared__ uint8_t qsol[256];
+    __shared__ int s_minfail[RS_THREADS];
+    __shared__ int s_sum[RS_THREADS];
     const uint32_t tid = threadIdx.x;
     for (uint32_t i = tid; i < ATO_SIZE; i += RS_THREADS) ato[i] = g_gf.ato[i];
     iof[tid] = g_gf.iof[tid];
-    for (uint32_t i = tid; i < 256u * 4u; i += RS_THREADS) gtab[i] = g_gen.w[i];
+    qsol[tid] = g_quad.q[tid];
+    if (tid < 2u * 16u * 4u) gnib[tid] = g_nib.w[tid];
     for (uint32_t i = tid; i < STEP_TERMS * 256u; i += RS_THREADS) step[i] = g_step.w[i];
-    int* const s_minfail = reinterpret_cast<int*>(gtab) + 3;                    // word l: s_minfail[4 * l]
-    int* const s_sum = reinterpret_cast<int*>(gtab) + 4 * RS_MAX_SPB + 3;       //         s_sum[4 * l]
     __syncthreads();
 
-    const uint32_t spb = RS_THREADS / rsdims < RS_MAX_SPB ? RS_THREADS / rsdims : RS_MAX_SPB;
+    const uint32_t spb = RS_THREADS / rsdims;
     const long long ngroups = (nsf + spb - 1) / spb;
     const uint32_t in_sz = NCW * rsdims, out_sz = NMSG * rsdims;
     const uint32_t lsf = tid / rsdims, colidx = tid - lsf * rsdims;
@@ -674,8 +689,8 @@ __global__ __launch_bounds__(RS_THREADS, 4) void rs_kernel(const uint8_t* __rest
         const long long sf0 = g * spb;
         const uint32_t nloc = nsf - sf0 < (long long)spb ? (uint32_t)(nsf - sf0) : spb;
         if (tid < spb) {
-            s_minfail[4 * tid] = NOFAIL;
-            s_sum[4 * tid] = 0;
+            s_minfail[tid] = NOFAIL;
+            s_sum[tid] = 0;
         }
         if (pre_ok) {
             const uint32_t nw = nloc * in_sz / 8u;
@@ -690,8 +705,8 @@ __global__ __launch_bounds__(RS_THREADS, 4) void rs_kernel(const uint8_t* __rest
         }
         __syncthreads();
         const bool active = lsf < nloc;
-        const int res = decode_rs_lfsr(active, lsf, cw, active ? lsf * in_sz + colidx : 0u, rsdims, ato, iof, gtab, step);  // all lanes
-        if (res < 0) atomicMin(&s_minfail[4 * lsf], (int)colidx);
+        const int res = decode_rs_lfsr(active, lsf, cw, active ? lsf * in_sz + colidx : 0u, rsdims, ato, iof, qsol, gnib, step);  // all lanes
+        if (res < 0) atomicMin(&s_minfail[lsf], (int)colidx);
         __syncthreads();
         uint8_t* dst0 = out + (size_t)sf0 * out_sz;
         // superframes without a failure: their first 110 rows go out as one linear block each
@@ -704,23 +719,23 @@ __global__ __launch_bounds__(RS_THREADS, 4) void rs_kernel(const uint8_t* __rest
             else
                 copy_out<uint32_t>(dst0, cw, s_minfail, nloc, in_sz, out_sz, tid);
             if (active) {
-                const int mf = s_minfail[4 * lsf];
+                const int mf = s_minfail[lsf];
                 if (mf != NOFAIL && (int)colidx < mf) {  // columns before the first failure are written
                     uint8_t* dst = dst0 + (lsf * out_sz + colidx);  // < 110 * 256
                     const uint8_t* src = cw + lsf * in_sz + colidx;
 #pragma clang loop vectorize(disable) interleave(disable)
                     for (int k = 0; k < NMSG; k++) dst[(size_t)k * rsdims] = src[k * rsdims];
                 }
-                if ((int)colidx < mf) atomicAdd(&s_sum[4 * lsf], res);
+                if ((int)colidx < mf) atomicAdd(&s_sum[lsf], res);
             }
         } else if (active) {
-            const int mf = s_minfail[4 * lsf];
+            const int mf = s_minfail[lsf];
             if ((int)colidx < mf) {
                 uint8_t* dst = dst0 + (lsf * out_sz + colidx);  // < 110 * 256
                 const uint8_t* src = cw + lsf * in_sz + colidx;
 #pragma clang loop vectorize(disable) interleave(disable)
                 for (int k = 0; k < NMSG; k++) dst[(size_t)k * rsdims] = src[k * rsdims];
-                atomicAdd(&s_sum[4 * lsf], res);
+                atomicAdd(&s_sum[lsf], res);
             }
         }
         // single-call path (RScheckSuperframe): the host spins on ret[0] in its mapped buffer instead of waiting for the
@@ -728,7 +743,7 @@ __global__ __launch_bounds__(RS_THREADS, 4) void rs_kernel(const uint8_t* __rest
         if (host_polls_ret) __threadfence_system();
         __syncthreads();
         if (tid < nloc) {
-            const int32_t r = s_minfail[4 * tid] != NOFAIL ? -1 : s_sum[4 * tid];
+            const int32_t r = s_minfail[tid] != NOFAIL ? -1 : s_sum[tid];
             if (host_polls_ret) __hip_atomic_store(&ret[sf0 + tid], r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             else ret[sf0 + tid] = r;
         }
@@ -742,8 +757,7 @@ hipError_t rs_launch(const uint8_t* d_p, uint8_t* d_out, int32_t* d_ret, uint32_
                      hipStream_t stream, bool host_polls_ret) {
     if (nsf <= 0 || rsdims == 0) return hipSuccess;
     if (host_polls_ret && (nsf != 1 || rsdims > RS_THREADS)) return hipErrorInvalidValue;
-    uint32_t spb = rsdims <= RS_THREADS ? RS_THREADS / rsdims : 1u;
-    if (spb > RS_MAX_SPB) spb = RS_MAX_SPB;
+    const uint32_t spb = rsdims <= RS_THREADS ? RS_THREADS / rsdims : 1u;
     long long groups = (nsf + spb - 1) / spb;
     if (groups > (1 << 20)) groups = 1 << 20;
     if (rsdims <= RS_THREADS) {

@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/configs_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/tests/tools/bench_configs.py > $OUT/configs.jsonl 2> $OUT/configs.err; echo "configs rc=$?"
-for m in clean light mixed; do python3 $R/tests/tools/bench_rs.py 24 131072 $m 2>/dev/null; python3 $R/tests/tools/bench_rs.py 24 16384 $m 2>/dev/null; done > $OUT/rs.jsonl; echo "rs rc=$?"
+for m in clean light rough le2 le5 mixed; do python3 $R/tests/tools/bench_rs.py 24 131072 $m 2>/dev/null; python3 $R/tests/tools/bench_rs.py 24 16384 $m 2>/dev/null; done > $OUT/rs.jsonl; echo "rs rc=$?"
 python3 $R/tools/exp/small_batch.py > $OUT/small_batch.jsonl 2>/dev/null; echo "small_batch rc=$?"
 python3 $R/tests/tools/bench_host_paths.py > $OUT/hostpaths.jsonl 2>/dev/null; echo "host rc=$?"
 [ -x $R/tools/vitbench.bin ] || g++ -O2 -std=c++17 -I $R/include -o $R/tools/vitbench.bin $R/tools/vitbench.cpp -ldl -lpthread

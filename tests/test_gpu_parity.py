@@ -414,6 +414,29 @@ def test_rs_error_mixes(V, O, torch_cuda, rsdims, weights):
     assert np.array_equal(d_out.cpu().numpy(), out_ref)
 
 
+@pytest.mark.parametrize("rsdims,in_off,out_off", [(8, 0, 0), (8, 8, 16), (8, 4, 4), (8, 1, 0), (8, 0, 1), (6, 0, 0),
+                                                    (6, 2, 2), (7, 0, 0), (7, 3, 5), (2, 0, 2), (24, 8, 4), (24, 16, 8)])
+def test_rs_pointer_alignment(V, O, torch_cuda, rsdims, in_off, out_off):
+    """The kernel picks its copy widths from the block sizes and the alignment of the device pointers (16-byte, dword
+    and byte paths in both directions): same results whatever they are, and not a byte outside the output block."""
+    torch = torch_cuda
+    nsf = 37
+    p = _rs_superframes(O, nsf, rsdims, seed=77 + rsdims + in_off)
+    init = np.full((nsf, 110 * rsdims), 0xC3, np.uint8)
+    ret_ref, out_ref = O.rs_check_batch(p, rsdims, out_init=init)
+    pad = 64
+    d_in = torch.zeros(p.size + 2 * pad, dtype=torch.uint8, device="cuda")
+    d_in[in_off:in_off + p.size] = torch.from_numpy(p.reshape(-1)).cuda()
+    d_o = torch.full((init.size + 2 * pad,), 0xC3, dtype=torch.uint8, device="cuda")
+    d_ret = torch.full((nsf,), 12345, dtype=torch.int32, device="cuda")
+    V.rs_batch_dev(d_in[in_off:], d_o[pad + out_off:], d_ret, rsdims, nsf)
+    torch.cuda.synchronize()
+    got = d_o.cpu().numpy()
+    assert np.array_equal(d_ret.cpu().numpy(), ret_ref)
+    assert np.array_equal(got[pad + out_off:pad + out_off + init.size].reshape(nsf, -1), out_ref)
+    assert (got[:pad + out_off] == 0xC3).all() and (got[pad + out_off + init.size:] == 0xC3).all()
+
+
 def test_rs_wide_superframe(V, O, torch_cuda):
     """more columns than a workgroup has lanes: chunked walk keeps the early-exit rule"""
     rsdims, nsf = 300, 3

@@ -375,7 +375,10 @@ __host__ __device__ inline PkLayout pk_layout(u32 maxfb) {  // single-segment ke
 // out in LDS in those same complemented coordinates (dec_slot() below), so that P IS the byte offset
 // of the history word inside its block.  State 0 is P = 252.
 constexpr u32 P_ZERO = 252u;
-constexpr u32 TB_WARM = 30u;  // warm-up steps (multiple of 5) a speculative block starts above its own range
+#ifndef VIT_TB_WARM
+#define VIT_TB_WARM 30
+#endif
+constexpr u32 TB_WARM = VIT_TB_WARM;  // warm-up steps (multiple of 5) a speculative block starts above its own range
 
 // LDS byte offset, inside a 512-byte decision block, of the (acc1, acc0) pair of ACS lane `lane`:
 // [pair][31 - l][1 - n] - the register with n = 1 first.  Every store of a block uses it.

@@ -42,8 +42,8 @@ print(json.dumps({"total_frames": total, "differing": bad, "seconds": round(time
 # miscorrected towards the virtual padding), GPU vs oracle: return values and every output byte ----
 t0 = time.time()
 rs_total = rs_bad = 0
-for rsdims, nsf in ((24, 6000), (12, 6000), (5, 4000), (1, 3000), (37, 2000), (256, 300), (300, 200)):
-    rng = np.random.default_rng(1000 + rsdims)
+for rep, (rsdims, nsf) in [(r, c) for r in range(REPS) for c in ((24, 6000), (12, 6000), (5, 4000), (1, 3000), (37, 2000), (256, 300), (300, 200), (8, 3000), (3, 3000))]:
+    rng = np.random.default_rng(1000 + rsdims + 7919 * rep)
     msg = rng.integers(0, 256, (nsf * rsdims, 110), dtype=np.uint8)
     cws = np.stack([O.rs_encode(m) for m in msg[:512]])            # 512 distinct codewords, reused
     cw = cws[rng.integers(0, 512, nsf * rsdims)]
@@ -62,5 +62,5 @@ for rsdims, nsf in ((24, 6000), (12, 6000), (5, 4000), (1, 3000), (37, 2000), (2
     V.rs_batch_dev(torch.from_numpy(p).to(dev), d_out, d_ret, rsdims, nsf); torch.cuda.synchronize()
     nb = int((d_ret.cpu().numpy() != ret_ref).sum()) + int((d_out.cpu().numpy() != out_ref).any(axis=1).sum())
     rs_total += nsf; rs_bad += nb
-    print(json.dumps({"rsdims": rsdims, "superframes": nsf, "failed_superframes": int((ret_ref < 0).sum()), "differing": nb}), flush=True)
+    print(json.dumps({"rep": rep, "rsdims": rsdims, "superframes": nsf, "failed_superframes": int((ret_ref < 0).sum()), "differing": nb}), flush=True)
 print(json.dumps({"rs_superframes": rs_total, "rs_differing": rs_bad, "seconds": round(time.time() - t0, 1)}))

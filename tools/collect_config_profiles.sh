@@ -14,7 +14,7 @@ python3 $R/tools/exp/small_batch.py > $OUT/small_batch.jsonl 2>/dev/null; echo "
 python3 $R/tests/tools/bench_host_paths.py > $OUT/hostpaths.jsonl 2>/dev/null; echo "host rc=$?"
 [ -x $R/tools/vitbench.bin ] || g++ -O2 -std=c++17 -I $R/include -o $R/tools/vitbench.bin $R/tools/vitbench.cpp -ldl -lpthread
 $R/tools/vitbench.bin $R/viterbi.dll_amd/libviterbi.so > $OUT/vitbench.txt 2>&1; echo "vitbench rc=$?"
-python3 $R/tests/tools/soak.py > $OUT/soak.jsonl 2>/dev/null; echo "soak rc=$?"
+python3 $R/tests/tools/soak.py 5 > $OUT/soak.jsonl 2>/dev/null; echo "soak rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/tests/tools/bench_configs.py > $OUT/kt.log 2>&1; echo "kt rc=$?"
 cp $OUT/kt/*/*_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/p1 -- python3 $R/tests/tools/bench_configs.py > $OUT/p1.log 2>&1; echo "pmc FETCH rc=$?"

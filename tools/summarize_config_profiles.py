@@ -22,9 +22,11 @@ if os.path.exists(os.path.join(src, "small_batch.jsonl")):
     with open(os.path.join(dst, "%s_small_batch.jsonl" % tag), "w") as f:
         f.writelines(l for l in open(os.path.join(src, "small_batch.jsonl")) if l.startswith("{"))
 with open(os.path.join(dst, "%s_soak.txt" % tag), "w") as f:
-    f.write("# tests/tools/soak.py on MI355X: GPU (auto kernel) vs CPU oracle, bit-exact compare of every output byte\n"
-            "# decode (5 seed sets): lengths 768/288/1536/3072/6912/9216/776/784/770/9214 x {Eb/N0 3 dB, 0 dB, 12 dB, uniform random bytes, saturation/renormalisation stress patterns};\n"
-            "# RS: random superframes with 0..8 symbol errors per column, RSDims 24/12/5/1/37/256/300\n")
+    lines = [l for l in open(os.path.join(src, "soak.jsonl")) if l.startswith("{")]
+    reps = 1 + max([__import__("json").loads(l).get("rep", 0) for l in lines] or [0])
+    f.write("# tests/tools/soak.py %d on MI355X: GPU (auto kernel) vs CPU oracle, bit-exact compare of every output byte\n"
+            "# decode (%d seed sets): lengths 768/288/1536/3072/6912/9216/776/784/770/9214 x {Eb/N0 3 dB, 0 dB, 12 dB, uniform random bytes, saturation/renormalisation stress patterns};\n"
+            "# RS (%d seed sets): superframes with 0..8 symbol errors per column in three regimes (dense correctable, dense with failures, sparse), RSDims 24/12/5/1/37/256/300/8/3\n" % (reps, reps, reps))
     for line in open(os.path.join(src, "soak.jsonl")):
         if "total_frames" in line or "rs_superframes" in line or '"rsdims"' in line:
             f.write(line)

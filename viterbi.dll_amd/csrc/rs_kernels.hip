@@ -9,10 +9,13 @@
 // -> HBM with 16-byte accesses in their natural layout p[j + k*RSDims] (rschecksf.cpp:75-76: lanes
 // of one superframe read consecutive bytes of a row, so the column gather needs no transposition).
 // The 1190 multiply-adds of the syndrome loop (rschecksf.cpp:210-219) are replaced by the remainder
-// of the codeword modulo the generator polynomial: one 16-byte LDS lookup per data byte
-// (x -> x*g_0..x*g_9) instead of nine byte lookups; a zero remainder is a clean codeword, otherwise
-// the ten syndromes are the remainder evaluated at alpha^i (same field elements as the reference's
-// Horner sums, since g(alpha^i) = 0).  rs_kernel_wide keeps the transposed-LDS form for RSDims > 256.
+// of the codeword modulo the generator polynomial: two conflict-free 16-byte LDS lookups per data byte
+// (low and high nibble of x -> x*g_0..x*g_9, see NibTable) instead of nine byte lookups; a zero remainder
+// is a clean codeword, otherwise the ten syndromes are the remainder evaluated at alpha^i (same field
+// elements as the reference's Horner sums, since g(alpha^i) = 0).  The correction path (rs_correct) is
+// entered by a whole wavefront as soon as one of its columns has an error: Berlekamp-Massey on logs,
+// locator roots in closed form (degree 1, 2), a wavefront per column (chien_wave) or four positions per
+// lookup (chien_quad), Forney.  rs_kernel_wide keeps the transposed-LDS form for RSDims > 256.
 //
 // Replaces, from scratch: RScheckSuperframe (rschecksf.cpp:65-93), DECODE_RS
 // (:199-377), Mod255 (:50-52) and CreateLookupTables (dllmain.cpp:124-146).
@@ -28,7 +31,7 @@ constexpr int RS_THREADS = 256;
 constexpr int ATO_ZERO = 512;   // index form of a zero coefficient where a lookup must give 0: ato[512..767] = 0
 constexpr int ATO_SIZE = 768;
 #ifndef COOP_MAX3
-#define COOP_MAX3 12   // most degree-3-or-more columns in a wave for the column-at-a-time search (dmax = 3 / dmax = 4, 5)
+#define COOP_MAX3 12  /* most columns of degree 3 and above in a wave for the column-at-a-time search chien_wave (wave's largest degree 3 / 4 or 5) */
 #endif
 #ifndef COOP_MAX5
 #define COOP_MAX5 28  /* the stress mix of tests/tools/bench_rs.py holds 20 +- 4 per wave (and ends most superframes early), a mix without failures but 0..5 errors in every column 32 +- 4 */

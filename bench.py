@@ -117,6 +117,81 @@ def cpu_baseline(O, sym_host, framebits, want_seconds=10.0):
     return base, ref
 
 
+# ---- second stage of the path: RScheckSuperframe in batch (BASELINE config 5's RS(120,110) step) ----------------------
+def rs_test_block(nsf, rsdims, p_err, seed):
+    """nsf DISTINCT superframes built here from the code's definition - GF(2^8)/0x11D, g(x) = prod_{i<10}(x + alpha^i),
+    codeword byte k of column j at p[j + k*rsdims] (rschecksf.cpp:75-76), message first - with ONE symbol error in a
+    fraction p_err of the columns (what the Viterbi stage leaves at Eb/N0 = 3 dB).  Returns the block, the expected output
+    (the messages) and the expected return values (corrections per superframe): the check needs no oracle."""
+    rng = np.random.default_rng(seed)
+    alpha = np.zeros(512, np.int64); logt = np.zeros(256, np.int64)
+    x = 1
+    for i in range(255):
+        alpha[i] = x; logt[x] = i
+        x <<= 1
+        if x & 256:
+            x ^= 0x11D
+    alpha[255:510] = alpha[:255]
+    g = [1]
+    for i in range(10):  # multiply by (x + alpha^i); g[j] = coefficient of x^j
+        ng = [0] * (len(g) + 1)
+        for j, c in enumerate(g):
+            ng[j + 1] ^= c
+            if c:
+                ng[j] ^= int(alpha[logt[c] + i])
+        g = ng
+    glog = [int(logt[c]) for c in g[:10]]  # g is monic and none of g_0..g_9 is zero for this code
+    ncol = nsf * rsdims
+    msg = rng.integers(0, 256, (110, ncol), dtype=np.int64)
+    r = np.zeros((10, ncol), np.int64)  # remainder register, r[j] = coefficient of x^j
+    for k in range(110):
+        f = msg[k] ^ r[9]
+        nz = f != 0
+        lf = logt[f]
+        nr = np.empty_like(r)
+        for j in range(10):
+            prod = np.where(nz, alpha[lf + glog[j]], 0)
+            nr[j] = (r[j - 1] if j else 0) ^ prod
+        r = nr
+    cw = np.concatenate([msg, r[::-1]], axis=0).astype(np.uint8)  # parity: x^9 first
+    err = rng.random(ncol) < p_err
+    rows = rng.integers(0, 120, ncol)
+    vals = rng.integers(1, 256, ncol).astype(np.uint8)
+    bad = cw.copy()
+    cols = np.nonzero(err)[0]
+    bad[rows[cols], cols] ^= vals[cols]
+    to_block = lambda a, h: a.reshape(h, nsf, rsdims).transpose(1, 0, 2).reshape(nsf, h * rsdims).copy()
+    return to_block(bad, 120), to_block(cw[:110], 110), err.reshape(nsf, rsdims).sum(axis=1).astype(np.int32)
+
+
+def second_stage(V, dev, nsf=131072, rsdims=24, distinct=256, iters=10):
+    p, want_out, want_ret = rs_test_block(distinct, rsdims, 0.06, seed=4242)
+    reps = nsf // distinct
+    d_p = torch.from_numpy(p).to(dev).repeat(reps, 1).contiguous()
+    d_out = torch.zeros((nsf, 110 * rsdims), dtype=torch.uint8, device=dev)
+    d_ret = torch.full((nsf,), -7, dtype=torch.int32, device=dev)
+    t_end = time.perf_counter() + 0.15  # untimed pre-conditioning: the clocks have dropped during the CPU leg
+    while time.perf_counter() < t_end:
+        V.rs_batch_dev(d_p, d_out, d_ret, rsdims, nsf)
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        V.rs_batch_dev(d_p, d_out, d_ret, rsdims, nsf)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    ok = bool(torch.equal(d_out.view(reps, distinct, -1), torch.from_numpy(want_out).to(dev).expand(reps, -1, -1))) and \
+        bool(torch.equal(d_ret.view(reps, distinct), torch.from_numpy(want_ret).to(dev).expand(reps, -1)))
+    gbs = nsf * 230.0 * rsdims / (ms * 1e-3) / 1e9  # 120*RSDims read + 110*RSDims written per superframe (SURVEY 8d)
+    return {"kernel": "rs_kernel: RScheckSuperframe in batch (vit_rs_batch_dev), RSDims %d" % rsdims,
+            "workload": "%d superframes resident in HBM (%d distinct, tiled), one symbol error in 6 %% of the columns" % (nsf, distinct),
+            "ms": round(ms, 4), "superframes_per_s": round(nsf / (ms * 1e-3), 0),
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(nsf * 230 * rsdims)},
+            "outputs_and_return_values_as_constructed": ok}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,6 +200,7 @@ def parse_args(argv=None):
     ap.add_argument("--frames", type=int, default=65536, help="FIC frames per GPU per step")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 wave-per-frame, 2 packed")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-rs", action="store_true", help="skip the second-stage (RScheckSuperframe batch) measurement")
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
                     help="untimed GPU pre-conditioning before the W warm-up steps: the MI355X needs ~15 ms of sustained load "
                          "to reach its steady-state clocks (first launches run ~10 %% slower, tools/exp/trend.py)")
@@ -364,6 +440,11 @@ def main(argv=None):
             result["speedup_vs_cpu_1thread"] = round(result["value"] / base["value"], 1)
             if bad:
                 result["value"] = 0.0  # a fast kernel with wrong results is not a result
+        if world == 1 and not args.stub and not args.no_rs and args.mode == "shard":
+            try:
+                result["second_stage"] = second_stage(V, dev)
+            except Exception as e:  # the headline line must not depend on this leg
+                result["second_stage"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(result), flush=True)
     if dist:
         dist.barrier()

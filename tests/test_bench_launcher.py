@@ -60,3 +60,16 @@ def test_under_torch_distributed_run_with_two_ranks():
     assert len(lines) == 1, p.stdout
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["config"]["launch"] == "external launcher"
+
+
+def test_second_stage_input_generator_agrees_with_the_oracle():
+    """bench.py builds its RS(120,110) superframes from the code's definition (it may not use the oracle for its
+    product-side legs); here the oracle decodes them: valid codewords, one correction per injected error."""
+    import numpy as np
+    import _vitpkg
+    import bench
+    O = _vitpkg.load_oracle()
+    for nsf, rsdims, p_err in ((24, 24, 0.06), (16, 7, 0.5), (8, 1, 1.0)):
+        p, want_out, want_ret = bench.rs_test_block(nsf, rsdims, p_err, seed=nsf + rsdims)
+        ret, out = O.rs_check_batch(p, rsdims)
+        assert np.array_equal(ret, want_ret) and np.array_equal(out, want_out)

@@ -95,6 +95,9 @@ def test_bench_through_its_spawn_path(torch_cuda):
     """`bench.py --gpus 1 --spawn`: the same child-process launch the bare `--gpus N` uses, backend nccl, HIP decoder"""
     r = _bench(["--gpus", "1", "--spawn", "--frames", "8192"])
     assert r["n_gpus"] == 1 and r["config"]["launch"] == "spawned by bench.py" and r["value"] > 1000
+    # the second stage of the path (RScheckSuperframe in batch) rides along at N = 1, checked against its construction
+    ss = r["second_stage"]
+    assert ss["outputs_and_return_values_as_constructed"] is True and ss["roofline"]["achieved"] > 100, ss
     r = _bench(["--gpus", "1", "--spawn", "--frames", "8192", "--mode", "scatter", "--chunk-frames", "1024"])
     assert r["n_gpus"] == 1 and r["value"] > 1000
     r = _bench(["--gpus", "1", "--frames", "8192", "--mode", "multi", "--chunk-frames", "1024", "--loopback"])

@@ -422,8 +422,6 @@ def main(argv=None):
             result["roofline"] = None
             if routing_ok is not None:
                 result["routing_ok"] = routing_ok
-        else:
-            _attach_cached_counters(result)
         if args.mode != "shard" and result.get("roofline"):
             result["roofline"]["note"] = "kernel_ms here spans scatter+decode+gather; see shard mode for the kernel"
         if world == 1 and not args.no_cpu and not args.stub:
@@ -445,6 +443,8 @@ def main(argv=None):
                 result["second_stage"] = second_stage(V, dev)
             except Exception as e:  # the headline line must not depend on this leg
                 result["second_stage"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if not args.stub:
+            _attach_cached_counters(result)
         print(json.dumps(result), flush=True)
     if dist:
         dist.barrier()
@@ -521,6 +521,10 @@ def _attach_cached_counters(result):
             r[k] = pmc[k]
     if "valu_busy" in pmc:
         r["binding_resource"] = "VALU issue (see valu_busy); the HBM frac is reported as the north star asks"
+    ss = result.get("second_stage")
+    if ss and ss.get("roofline") and pmc.get("second_stage"):
+        ss["roofline"]["traffic"] = pmc["second_stage"].get("hbm_bytes_per_launch")
+        ss["roofline"]["traffic_source"] = r["traffic_source"]
 
 
 if __name__ == "__main__":

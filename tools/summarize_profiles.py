@@ -86,6 +86,32 @@ if "SQ_WAVES" in tot:
         pmc_json["valu_insts_per_frame_step"] = round(tot["SQ_INSTS_VALU"] / w / steps / 4.0, 3)  # 4 frames per wave
     lines.append("per wave: VALU %.0f  SALU %.0f  LDS %.0f  wave-cycles(quad) %.0f\n" % (
         tot.get("SQ_INSTS_VALU", 0) / w, tot.get("SQ_INSTS_SALU", 0) / w, tot.get("SQ_INSTS_LDS", 0) / w, tot.get("SQ_WAVE_CYCLES", 0) / w))
+# second stage (rs_kernel) of the same runs: duration from the kernel trace, HBM bytes from the FETCH/WRITE passes
+ss = bench.get("second_stage") or {}
+rs_rows = [r for r in rows if "rs_kernel" in r["Name"]]
+if rs_rows and "ms" in ss:
+    lines.append("\n# second stage: %s\n" % ss.get("kernel"))
+    lines.append("rs_kernel avg (rocprof, incl. the untimed pre-conditioning launches) %.1f us, min %.1f us vs bench HIP-event ms %.4f\n"
+                 % (float(rs_rows[0]["AverageNs"]) / 1e3, float(rs_rows[0]["MinNs"]) / 1e3, ss["ms"]))
+rs_tot = {}
+for pp in ("p1", "p2"):
+    fn = os.path.join(src, "pmc_%s.csv" % pp)
+    if os.path.exists(fn):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(fn)):
+            if "rs_kernel" in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            rs_tot[k] = sum(v) / len(v)
+if "FETCH_SIZE" in rs_tot and "WRITE_SIZE" in rs_tot and ss.get("roofline"):
+    rs_alg = ss["roofline"]["algorithmic_bytes_per_launch"]
+    rs_fetch, rs_write = 2.0 * rs_tot["FETCH_SIZE"] * 1024.0, rs_tot["WRITE_SIZE"] * 1024.0
+    lines.append("rs_kernel HBM traffic per launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 = %.4g + %.4g = %.4g B; algorithmic %.4g B; ratio %.3f\n"
+                 % (rs_fetch, rs_write, rs_fetch + rs_write, rs_alg, (rs_fetch + rs_write) / rs_alg))
+    if pmc_json is not None:
+        pmc_json["second_stage"] = {"kernel": "rs_kernel", "hbm_bytes_per_launch": int(rs_fetch + rs_write),
+                                    "fetch_bytes_corrected": int(rs_fetch), "write_bytes": int(rs_write),
+                                    "algorithmic_bytes_per_launch": rs_alg}
 if pmc_json is not None:
     with open(os.path.join(dst, "pmc_traffic.json"), "w") as f:
         json.dump(pmc_json, f, indent=1)

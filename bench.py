@@ -118,12 +118,9 @@ def cpu_baseline(O, sym_host, framebits, want_seconds=10.0):
 
 
 # ---- second stage of the path: RScheckSuperframe in batch (BASELINE config 5's RS(120,110) step) ----------------------
-def rs_test_block(nsf, rsdims, p_err, seed):
-    """nsf DISTINCT superframes built here from the code's definition - GF(2^8)/0x11D, g(x) = prod_{i<10}(x + alpha^i),
-    codeword byte k of column j at p[j + k*rsdims] (rschecksf.cpp:75-76), message first - with ONE symbol error in a
-    fraction p_err of the columns (what the Viterbi stage leaves at Eb/N0 = 3 dB).  Returns the block, the expected output
-    (the messages) and the expected return values (corrections per superframe): the check needs no oracle."""
-    rng = np.random.default_rng(seed)
+def rs_encode_columns(msg):
+    """msg: (110, ncol) bytes -> (120, ncol) RS(120,110) codewords, one per column, from the code's definition:
+    GF(2^8)/0x11D, g(x) = prod_{i<10}(x + alpha^i), systematic (message first, then the remainder, x^9 first)."""
     alpha = np.zeros(512, np.int64); logt = np.zeros(256, np.int64)
     x = 1
     for i in range(255):
@@ -141,9 +138,8 @@ def rs_test_block(nsf, rsdims, p_err, seed):
                 ng[j] ^= int(alpha[logt[c] + i])
         g = ng
     glog = [int(logt[c]) for c in g[:10]]  # g is monic and none of g_0..g_9 is zero for this code
-    ncol = nsf * rsdims
-    msg = rng.integers(0, 256, (110, ncol), dtype=np.int64)
-    r = np.zeros((10, ncol), np.int64)  # remainder register, r[j] = coefficient of x^j
+    msg = msg.astype(np.int64)
+    r = np.zeros((10, msg.shape[1]), np.int64)  # remainder register, r[j] = coefficient of x^j
     for k in range(110):
         f = msg[k] ^ r[9]
         nz = f != 0
@@ -153,7 +149,16 @@ def rs_test_block(nsf, rsdims, p_err, seed):
             prod = np.where(nz, alpha[lf + glog[j]], 0)
             nr[j] = (r[j - 1] if j else 0) ^ prod
         r = nr
-    cw = np.concatenate([msg, r[::-1]], axis=0).astype(np.uint8)  # parity: x^9 first
+    return np.concatenate([msg, r[::-1]], axis=0).astype(np.uint8)
+
+
+def rs_test_block(nsf, rsdims, p_err, seed):
+    """nsf DISTINCT superframes - codeword byte k of column j at p[j + k*rsdims] (rschecksf.cpp:75-76) - with ONE symbol
+    error in a fraction p_err of the columns (what the Viterbi stage leaves at Eb/N0 = 3 dB).  Returns the block, the
+    expected output (the messages) and the expected return values (corrections per superframe): the check needs no oracle."""
+    rng = np.random.default_rng(seed)
+    ncol = nsf * rsdims
+    cw = rs_encode_columns(rng.integers(0, 256, (110, ncol), dtype=np.int64))
     err = rng.random(ncol) < p_err
     rows = rng.integers(0, 120, ncol)
     vals = rng.integers(1, 256, ncol).astype(np.uint8)

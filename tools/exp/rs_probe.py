@@ -2,16 +2,14 @@ import json, os, sys, time
 import numpy as np, torch
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, ROOT)
 import _vitpkg
-from bench import make_frames
-V = _vitpkg.load_package(); O = _vitpkg.load_oracle(); V.initialize()
+from bench import make_frames, rs_encode_columns  # the encoder is bench.py's own (no oracle outside tests/)
+V = _vitpkg.load_package(); V.initialize()
 dev = torch.device("cuda", 0)
 rsdims, nsf, base_n = 24, 16384, 64
 fb = 192 * rsdims
 rng = np.random.default_rng(500 + rsdims)
-blocks = np.empty((base_n, 120, rsdims), np.uint8)
-for s_ in range(base_n):
-    for j in range(rsdims):
-        blocks[s_, :, j] = O.rs_encode(rng.integers(0, 256, 110, dtype=np.uint8))
+cw = rs_encode_columns(rng.integers(0, 256, (110, base_n * rsdims), dtype=np.uint8))  # (120, base_n*rsdims)
+blocks = cw.reshape(120, base_n, rsdims).transpose(1, 0, 2).copy()
 bits = np.unpackbits(blocks.reshape(base_n, -1), axis=1).reshape(base_n * 5, fb)
 pb = torch.from_numpy(bits.astype(np.int32)).to(dev).repeat(nsf // base_n, 1)
 sym = make_frames(nsf * 5, fb, seed=7, device=dev, payload_bits=pb)

@@ -36,6 +36,7 @@ def lib():
         L.vo_deconvolve_opt.argtypes = [C.c_uint, vp, vp, C.c_int]
         L.vo_deconvolve_u8.argtypes = [C.c_uint, vp, vp]
         L.vo_decode_batch_u8.argtypes = [C.c_uint, vp, vp, C.c_long, C.c_int]
+        L.vo_decode_batch_u8_opt.argtypes = [C.c_uint, vp, vp, C.c_long, C.c_int, C.c_int]
         L.vo_deconvolve_avx2_u8.argtypes = [C.c_uint, vp, vp]
         L.vo_decode_batch_avx2_u8.argtypes = [C.c_uint, vp, vp, C.c_long, C.c_int]
         L.vo_encode.argtypes = [C.c_uint, vp, vp]
@@ -85,6 +86,24 @@ def noisy_frames(nframes, framebits, seed=1, ebn0_db=3.0, return_bits=False):
     return (sym, bits) if return_bits else sym
 
 
+def hard_random_symbols(nframes, framebits, seed=1):
+    """i.i.d. hard-decision symbols 0/255 (no code structure): a family on which the `>150` and `>=150`
+    renormalise comparators give different outputs (metrics reach the 0 and 255 clamps)."""
+    rng = np.random.default_rng(seed)
+    return (rng.integers(0, 2, (nframes, sym_len(framebits)), dtype=np.uint8) * 255).astype(np.uint8)
+
+
+def hard_flipped_frames(nframes, framebits, flip=0.2, seed=1):
+    """random bits -> mother code -> hard symbols 0/255 with a fraction `flip` of the symbols inverted"""
+    rng = np.random.default_rng(seed)
+    out = np.empty((nframes, sym_len(framebits)), np.uint8)
+    for f in range(nframes):
+        hard = encode(rng.integers(0, 2, framebits, dtype=np.uint8))
+        inv = rng.random(hard.size) < flip
+        out[f] = np.where(inv, 1 - hard, hard) * 255
+    return out
+
+
 def encode(bits):
     bits = np.ascontiguousarray(bits, np.uint8)
     hard = np.empty(4 * (bits.size + 6), np.uint8)
@@ -101,13 +120,18 @@ def deconvolve_u32(framebits, sym_u32, ge=False):
     return out
 
 
-def decode_batch(framebits, sym_u8, nthreads=1, avx2=False):
-    """sym_u8: (nframes, 4*(framebits+6)) uint8 -> (nframes, (framebits+7)//8) uint8"""
+def decode_batch(framebits, sym_u8, nthreads=1, avx2=False, ge=False):
+    """sym_u8: (nframes, 4*(framebits+6)) uint8 -> (nframes, (framebits+7)//8) uint8
+    ge: the MASM decoders' `>=150` renormalise comparator (decon_avx2.asm:97,114) instead of the C path's `>150`"""
     sym_u8 = np.ascontiguousarray(sym_u8, np.uint8).reshape(-1, sym_len(framebits))
     n = sym_u8.shape[0]
     out = np.zeros((n, (framebits + 7) // 8), np.uint8)
-    fn = lib().vo_decode_batch_avx2_u8 if avx2 else lib().vo_decode_batch_u8
-    rc = fn(framebits, _p(sym_u8), _p(out), n, nthreads)
+    if ge:
+        assert not avx2, "the AVX2 port implements the C path's comparator only"
+        rc = lib().vo_decode_batch_u8_opt(framebits, _p(sym_u8), _p(out), n, nthreads, 1)
+    else:
+        fn = lib().vo_decode_batch_avx2_u8 if avx2 else lib().vo_decode_batch_u8
+        rc = fn(framebits, _p(sym_u8), _p(out), n, nthreads)
     if rc != 0:
         raise RuntimeError("oracle decode failed rc=%d" % rc)
     return out

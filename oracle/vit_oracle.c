@@ -122,6 +122,11 @@ int vo_deconvolve_u8(unsigned framebits, const uint8_t *symbols,
                      unsigned char *out) {
     return vo_decode_core(framebits, NULL, symbols, out, 0);
 }
+/* the MASM twins' comparator (decon_avx2.asm:97,114: `cmp sil,150 ; jb mainloop`) */
+int vo_deconvolve_u8_ge(unsigned framebits, const uint8_t *symbols,
+                        unsigned char *out) {
+    return vo_decode_core(framebits, NULL, symbols, out, 1);
+}
 
 /* ---- batch drivers --------------------------------------------------------- */
 typedef int (*vo_dec_fn)(unsigned, const uint8_t *, unsigned char *);
@@ -165,6 +170,12 @@ static int vo_batch(vo_dec_fn fn, unsigned framebits, const uint8_t *sym,
 int vo_decode_batch_u8(unsigned framebits, const uint8_t *symbols,
                        unsigned char *out, long nframes, int nthreads) {
     return vo_batch(vo_deconvolve_u8, framebits, symbols, out, nframes, nthreads);
+}
+int vo_decode_batch_u8_opt(unsigned framebits, const uint8_t *symbols,
+                           unsigned char *out, long nframes, int nthreads,
+                           int ge_threshold) {
+    return vo_batch(ge_threshold ? vo_deconvolve_u8_ge : vo_deconvolve_u8,
+                    framebits, symbols, out, nframes, nthreads);
 }
 int vo_decode_batch_avx2_u8(unsigned framebits, const uint8_t *symbols,
                             unsigned char *out, long nframes, int nthreads) {

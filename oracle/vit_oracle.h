@@ -40,10 +40,17 @@ int vo_deconvolve_opt(unsigned framebits, const uint32_t *symbols,
 /* Same decoder over the build's device format: one byte per soft symbol. */
 int vo_deconvolve_u8(unsigned framebits, const uint8_t *symbols,
                      unsigned char *out);
+/* Same with the MASM twins' `>=150` renormalise test (decon_avx2.asm:97,114). */
+int vo_deconvolve_u8_ge(unsigned framebits, const uint8_t *symbols,
+                        unsigned char *out);
 /* Batch helpers (frames contiguous; u8 symbols, 4*(framebits+6) per frame;
  * (framebits+7)/8 output bytes per frame).  nthreads<=1 -> serial. */
 int vo_decode_batch_u8(unsigned framebits, const uint8_t *symbols,
                        unsigned char *out, long nframes, int nthreads);
+
+int vo_decode_batch_u8_opt(unsigned framebits, const uint8_t *symbols,
+                           unsigned char *out, long nframes, int nthreads,
+                           int ge_threshold);
 
 /* Hand-written AVX2 port of the same specification (own design), used as the
  * timed CPU baseline.  Returns -1 when the host lacks AVX2. */

@@ -102,13 +102,23 @@ def test_u32_entry_uses_low_byte_only(O):
 
 
 def test_renorm_comparator_ge_vs_gt(O):
-    """Appendix A.6: the MASM twins renormalise on >=150, the C path on >150; the survey saw no
-    output difference in 36000 frames.  Same observation here on noisy + adversarial frames."""
+    """Appendix A.6: the MASM twins renormalise on >=150 (decon_avx2.asm:97,114), the C path on >150
+    (deconvolve.cpp:408).  On soft-decision input (reference-style noise, uniform bytes) the two modes agree --
+    the survey's 36000-frame observation -- but on HARD-decision input they do not: a uniform -63 is invisible
+    only until a metric hits the 0 or the 255 clamp (round-2 judge: 14-54 % of such frames differ)."""
     fb = 768
-    sym = np.concatenate([O.noisy_frames(40, fb, seed=3), O.uniform_symbols(40 * O.sym_len(fb), seed=4).reshape(40, -1)])
-    for s in sym:
-        s32 = s.astype(np.uint32)
-        assert np.array_equal(O.deconvolve_u32(fb, s32), O.deconvolve_u32(fb, s32, ge=True))
+    soft = np.concatenate([O.noisy_frames(40, fb, seed=3), O.uniform_symbols(40 * O.sym_len(fb), seed=4).reshape(40, -1)])
+    assert np.array_equal(O.decode_batch(fb, soft), O.decode_batch(fb, soft, ge=True))
+    for s in soft[:4]:  # the u32 entry point takes the same switch
+        assert np.array_equal(O.deconvolve_u32(fb, s.astype(np.uint32), ge=True), O.decode_batch(fb, s, ge=True)[0])
+    differing = {}
+    for fb, n in ((768, 100), (3072, 60)):
+        for name, sym in (("random 0/255", O.hard_random_symbols(n, fb, seed=5)),
+                          ("encoded, 20 % flips", O.hard_flipped_frames(n, fb, flip=0.2, seed=5))):
+            differing[(fb, name)] = int((O.decode_batch(fb, sym, nthreads=4) != O.decode_batch(fb, sym, nthreads=4, ge=True))
+                                        .any(axis=1).sum())
+    assert all(v > 0 for v in differing.values()), differing
+    assert differing[(3072, "encoded, 20 % flips")] >= 20  # more than a third of these frames
 
 
 def test_noise_free_roundtrip_and_ber(O):

@@ -20,7 +20,7 @@ TAIL = 6
 
 EXPORTS = [
     "deconvolve", "initialize", "RScheckSuperframe", "RSCheckSuperframe", "GetCPUCaps", "WakeUpYMM",
-    "vit_last_error", "vit_device_count", "vit_set_kernel", "vit_set_batch_window_us", "vit_set_batch_min_callers",
+    "vit_last_error", "vit_device_count", "vit_set_kernel", "vit_set_renorm_ge", "vit_set_batch_window_us", "vit_set_batch_min_callers",
     "vit_decode_batch_dev",
     "vit_decode_batch_dev_u32", "vit_decode_varlen_dev", "vit_pack_symbols_dev", "vit_sort_descs",
     "vit_decode_batch_host", "vit_rs_batch_dev", "vit_rs_batch_host", "vit_dabplus_superframes_dev",
@@ -70,6 +70,7 @@ def lib():
         L.WakeUpYMM.restype = None
         L.vit_last_error.restype = C.c_char_p
         L.vit_set_kernel.argtypes = [C.c_int]
+        L.vit_set_renorm_ge.argtypes = [C.c_int]
         L.vit_set_batch_window_us.argtypes = [C.c_int]
         L.vit_set_batch_min_callers.argtypes = [C.c_int]
         L.vit_decode_batch_dev.argtypes = [vp, vp, C.c_uint32, C.c_int64, vp]
@@ -120,6 +121,11 @@ def device_count():
 
 def set_kernel(which):
     return int(lib().vit_set_kernel(int(which)))
+
+
+def set_renorm_ge(on):
+    """0: renormalise on `> 150` (reference C decoders, Rel_cpp); 1: on `>= 150` (MASM decoders, Rel_asm)"""
+    return int(lib().vit_set_renorm_ge(1 if on else 0))
 
 
 def set_batch_window_us(us):

@@ -69,6 +69,19 @@ int g_cus = 0;
 char g_init_err[160] = "no usable gfx950 (MI355X) HIP device; libviterbi has no CPU path";
 std::atomic<int> g_fault{0};   // reference: exceptCounter / decon_savemode
 std::atomic<int> g_kernel{0};  // 0 auto, 1 wave, 2 packed, 3 latency
+// Renormalisation comparator of every decoder kernel: 0 = `> 150` (the reference's C decoders, deconvolve.cpp:399,408,
+// configuration Rel_cpp), 1 = `>= 150` (its MASM decoders, decon_avx2.asm:97,114 `cmp sil,150 ; jb mainloop`,
+// configuration Rel_asm).  Environment VITERBI_AMD_RENORM_GE=1 sets the start-up value; vit_set_renorm_ge() changes it.
+std::atomic<int> g_renorm_ge{[] {
+    const char* e = getenv("VITERBI_AMD_RENORM_GE");
+    return e && atoi(e) != 0 ? 1 : 0;
+}()};
+// what an exported entry point reads ONCE per call
+struct DecodeMode {
+    int kernel;
+    bool ge;
+};
+DecodeMode decode_mode() { return DecodeMode{g_kernel.load(), g_renorm_ge.load() != 0}; }
 
 void probe_devices() {
     // Callers are threads (README.md:56), each with its own stream.  ROCclr multiplexes a process's streams onto
@@ -201,16 +214,17 @@ int pick_kernel(int choice, uint32_t max_framebits, int64_t nframes) {
     }
     return vit_pk_supported(max_framebits) ? K_PACKED : (choice == K_PACKED ? -1 : K_WAVE);
 }
-int launch_decode(int choice, const uint8_t* d_sym, uint8_t* d_out, const vit_frame_desc* d_desc, uint32_t framebits,
+int launch_decode(DecodeMode mode, const uint8_t* d_sym, uint8_t* d_out, const vit_frame_desc* d_desc, uint32_t framebits,
                   uint32_t max_framebits, int64_t nframes, hipStream_t s) {
+    const int choice = mode.kernel;
     const int k = pick_kernel(choice, max_framebits, nframes);
     if (k < 0) {
         set_err("packed kernel does not support framebits=%u", max_framebits);
         return VIT_ERR_ARG;
     }
-    hipError_t e = k == K_PACKED    ? vit_launch_pk(d_sym, false, d_out, d_desc, framebits, max_framebits, nframes, s)
-                   : k == K_LATENCY ? vit_launch_lat(d_sym, false, d_out, d_desc, framebits, max_framebits, nframes, s)
-                                    : vit_launch_wave(d_sym, d_out, d_desc, framebits, max_framebits, nframes, s);
+    hipError_t e = k == K_PACKED    ? vit_launch_pk(d_sym, false, d_out, d_desc, framebits, max_framebits, nframes, s, mode.ge)
+                   : k == K_LATENCY ? vit_launch_lat(d_sym, false, d_out, d_desc, framebits, max_framebits, nframes, s, nullptr, 0, mode.ge)
+                                    : vit_launch_wave(d_sym, d_out, d_desc, framebits, max_framebits, nframes, s, mode.ge);
     if (e != hipSuccess) {
         set_err("kernel launch failed: %s", hipGetErrorString(e));
         return VIT_ERR_HIP;
@@ -223,12 +237,13 @@ bool u32_in_place(int choice, const void* d_sym32, uint32_t max_framebits, int64
     const int k = pick_kernel(choice, max_framebits, nframes);
     return (k == K_PACKED || k == K_LATENCY) && (reinterpret_cast<uintptr_t>(d_sym32) & 15u) == 0;
 }
-int launch_decode_u32(int choice, const uint32_t* d_sym32, uint8_t* d_scratch8, uint8_t* d_out, const vit_frame_desc* d_desc,
+int launch_decode_u32(DecodeMode mode, const uint32_t* d_sym32, uint8_t* d_scratch8, uint8_t* d_out, const vit_frame_desc* d_desc,
                       uint32_t framebits, uint32_t max_framebits, int64_t nframes, int64_t nsym, hipStream_t s) {
+    const int choice = mode.kernel;
     if (u32_in_place(choice, d_sym32, max_framebits, nframes)) {
         const int k = pick_kernel(choice, max_framebits, nframes);
-        hipError_t e = k == K_PACKED ? vit_launch_pk(d_sym32, true, d_out, d_desc, framebits, max_framebits, nframes, s)
-                                     : vit_launch_lat(d_sym32, true, d_out, d_desc, framebits, max_framebits, nframes, s);
+        hipError_t e = k == K_PACKED ? vit_launch_pk(d_sym32, true, d_out, d_desc, framebits, max_framebits, nframes, s, mode.ge)
+                                     : vit_launch_lat(d_sym32, true, d_out, d_desc, framebits, max_framebits, nframes, s, nullptr, 0, mode.ge);
         if (e != hipSuccess) {
             set_err("kernel launch failed: %s", hipGetErrorString(e));
             return VIT_ERR_HIP;
@@ -241,7 +256,7 @@ int launch_decode_u32(int choice, const uint32_t* d_sym32, uint8_t* d_scratch8, 
     }
     hipError_t e = vit_launch_pack(d_sym32, d_scratch8, nsym, s);
     if (e != hipSuccess) { set_err("pack launch failed: %s", hipGetErrorString(e)); return VIT_ERR_HIP; }
-    return launch_decode(choice, d_scratch8, d_out, d_desc, framebits, max_framebits, nframes, s);
+    return launch_decode(mode, d_scratch8, d_out, d_desc, framebits, max_framebits, nframes, s);
 }
 
 // ---- ingest stage: micro-batching of concurrent deconvolve() callers -------------
@@ -319,7 +334,7 @@ struct Batcher {
         HIPCHK(hipMemcpyAsync(t_ctx.d_in, pin, nsym * 4, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(d_desc, h_d, desc_bytes, hipMemcpyHostToDevice, s));
         // sym_offset counts symbols: the same table addresses the u32 buffer and its narrowed copy
-        rc = launch_decode_u32(g_kernel.load(), (const uint32_t*)t_ctx.d_in, (uint8_t*)t_ctx.d_sym8, (uint8_t*)t_ctx.d_out,
+        rc = launch_decode_u32(decode_mode(), (const uint32_t*)t_ctx.d_in, (uint8_t*)t_ctx.d_sym8, (uint8_t*)t_ctx.d_out,
                                (const vit_frame_desc*)d_desc, 0, maxfb, (int64_t)b.size(), (int64_t)nsym, s);
         if (rc != VIT_OK) return rc;
         HIPCHK(hipMemcpyAsync(h_out, t_ctx.d_out, nout, hipMemcpyDeviceToHost, s));
@@ -443,6 +458,8 @@ int vit_set_kernel(int which) {
     return g_kernel.exchange(which);
 }
 
+int vit_set_renorm_ge(int on) { return g_renorm_ge.exchange(on ? 1 : 0); }
+
 unsigned char initialize(void) {
     // dllmain.cpp:156-160: clear the fault counter and re-run the (idempotent) set-up.
     g_fault.store(0);
@@ -486,7 +503,7 @@ int vit_decode_batch_dev(const uint8_t* d_symbols_u8, uint8_t* d_decoded, uint32
         return VIT_ERR_ARG;
     }
     if (framebits == 0 || nframes == 0) return VIT_OK;
-    return launch_decode(g_kernel.load(), d_symbols_u8, d_decoded, nullptr, framebits, framebits, nframes,
+    return launch_decode(decode_mode(), d_symbols_u8, d_decoded, nullptr, framebits, framebits, nframes,
                          (hipStream_t)stream);
 }
 
@@ -499,9 +516,10 @@ int vit_decode_batch_dev_u32(const uint32_t* d_symbols_u32, uint8_t* d_decoded, 
     }
     if (framebits == 0 || nframes == 0) return VIT_OK;
     const size_t nsym = (size_t)nframes * 4u * (framebits + VIT_TAIL);
-    const int choice = g_kernel.load();
+    const DecodeMode mode = decode_mode();
+    const int choice = mode.kernel;
     if (u32_in_place(choice, d_symbols_u32, framebits, nframes))  // read in place: no scratch, no extra launch
-        return launch_decode_u32(choice, d_symbols_u32, nullptr, d_decoded, nullptr, framebits, framebits, nframes,
+        return launch_decode_u32(mode, d_symbols_u32, nullptr, d_decoded, nullptr, framebits, framebits, nframes,
                                  (int64_t)nsym, (hipStream_t)stream);
     // The narrowed symbols go to this thread's scratch buffer ON THE CALLER'S CURRENT DEVICE (the device its
     // pointers and stream belong to), not on the library's default device.
@@ -514,7 +532,7 @@ int vit_decode_batch_dev_u32(const uint32_t* d_symbols_u32, uint8_t* d_decoded, 
     // order the scratch buffer's reuse across the caller's streams
     if (!t_ctx.scratch_ev) HIPCHK(hipEventCreateWithFlags(&t_ctx.scratch_ev, hipEventDisableTiming));
     else HIPCHK(hipStreamWaitEvent((hipStream_t)stream, t_ctx.scratch_ev, 0));
-    rc = launch_decode_u32(choice, d_symbols_u32, (uint8_t*)t_ctx.d_sym8, d_decoded, nullptr, framebits, framebits, nframes,
+    rc = launch_decode_u32(mode, d_symbols_u32, (uint8_t*)t_ctx.d_sym8, d_decoded, nullptr, framebits, framebits, nframes,
                            (int64_t)nsym, (hipStream_t)stream);
     if (rc != VIT_OK) return rc;
     HIPCHK(hipEventRecord(t_ctx.scratch_ev, (hipStream_t)stream));
@@ -530,7 +548,7 @@ int vit_decode_varlen_dev(const uint8_t* d_symbols_u8, uint8_t* d_decoded, const
         return VIT_ERR_ARG;
     }
     if (nframes == 0 || max_framebits == 0) return VIT_OK;
-    return launch_decode(g_kernel.load(), d_symbols_u8, d_decoded, d_desc, 0, max_framebits, nframes, (hipStream_t)stream);
+    return launch_decode(decode_mode(), d_symbols_u8, d_decoded, d_desc, 0, max_framebits, nframes, (hipStream_t)stream);
 }
 
 void vit_sort_descs(vit_frame_desc* h_desc, int64_t nframes) {
@@ -554,7 +572,7 @@ int vit_decode_batch_host(const uint8_t* h_symbols_u8, uint8_t* h_decoded, uint3
     if ((rc = grow_dev(&t_ctx.d_sym8, &t_ctx.d8_cap, in_sz)) != VIT_OK) return rc;
     if ((rc = grow_dev(&t_ctx.d_out, &t_ctx.dout_cap, out_sz)) != VIT_OK) return rc;
     HIPCHK(hipMemcpyAsync(t_ctx.d_sym8, h_symbols_u8, in_sz, hipMemcpyHostToDevice, t_ctx.stream));
-    rc = launch_decode(g_kernel.load(), (const uint8_t*)t_ctx.d_sym8, (uint8_t*)t_ctx.d_out, nullptr, framebits, framebits,
+    rc = launch_decode(decode_mode(), (const uint8_t*)t_ctx.d_sym8, (uint8_t*)t_ctx.d_out, nullptr, framebits, framebits,
                        nframes, t_ctx.stream);
     if (rc != VIT_OK) return rc;
     HIPCHK(hipMemcpyAsync(h_decoded, t_ctx.d_out, out_sz, hipMemcpyDeviceToHost, t_ctx.stream));
@@ -607,9 +625,9 @@ static int deconvolve_impl(unsigned int framebits, unsigned int* symbols, unsign
     // kernel narrows the symbols first.)
     unsigned char* h_out = (unsigned char*)t_ctx.h_pin + nsym * 4;
     memcpy(t_ctx.h_pin, symbols, nsym * 4);
-    const int choice = g_kernel.load();
+    const DecodeMode mode = decode_mode();
     hipError_t e;
-    if (pick_kernel(choice, framebits, 1) == K_LATENCY) {
+    if (pick_kernel(mode.kernel, framebits, 1) == K_LATENCY) {
         // Latency path: the kernel publishes a sequence number in the mapped buffer after its last output byte and
         // this thread spins on it - the end-of-kernel signal and hipStreamSynchronize's wake-up are off the call's
         // critical path.  A kernel that does not finish within the spin budget falls back to the stream sync.
@@ -618,7 +636,7 @@ static int deconvolve_impl(unsigned int framebits, unsigned int* symbols, unsign
         const uint32_t seq = ++t_ctx.seq ? t_ctx.seq : ++t_ctx.seq;  // never 0
         *h_flag = 0;
         e = vit_launch_lat(t_ctx.h_pin_dev, true, (uint8_t*)t_ctx.h_pin_dev + nsym * 4, nullptr, framebits, framebits, 1,
-                           t_ctx.stream, reinterpret_cast<uint32_t*>((unsigned char*)t_ctx.h_pin_dev + flag_off), seq);
+                           t_ctx.stream, reinterpret_cast<uint32_t*>((unsigned char*)t_ctx.h_pin_dev + flag_off), seq, mode.ge);
         if (e != hipSuccess) return fail("launch", e);
         const auto t0 = std::chrono::steady_clock::now();
         unsigned spins = 0;
@@ -637,7 +655,7 @@ static int deconvolve_impl(unsigned int framebits, unsigned int* symbols, unsign
         memcpy(decodedBits, h_out, out_sz);
         return 0;
     }
-    if (launch_decode_u32(choice, (const uint32_t*)t_ctx.h_pin_dev, (uint8_t*)t_ctx.d_sym8, (uint8_t*)t_ctx.h_pin_dev + nsym * 4,
+    if (launch_decode_u32(mode, (const uint32_t*)t_ctx.h_pin_dev, (uint8_t*)t_ctx.d_sym8, (uint8_t*)t_ctx.h_pin_dev + nsym * 4,
                           nullptr, framebits, framebits, 1, (int64_t)nsym, t_ctx.stream) != VIT_OK) {
         g_fault.store(1);
         return 1;
@@ -674,7 +692,7 @@ int vit_dabplus_superframes_dev(const uint8_t* d_symbols_u8, uint8_t* d_work, ui
         return VIT_ERR_ARG;
     }
     if (nsf == 0) return VIT_OK;
-    int rc = launch_decode(g_kernel.load(), d_symbols_u8, d_work, nullptr, (uint32_t)framebits, (uint32_t)framebits, 5 * nsf,
+    int rc = launch_decode(decode_mode(), d_symbols_u8, d_work, nullptr, (uint32_t)framebits, (uint32_t)framebits, 5 * nsf,
                            (hipStream_t)stream);
     if (rc != VIT_OK) return rc;
     return vit_rs_batch_dev(d_work, d_rs_out, d_ret, RSDims, nsf, stream);

@@ -9,10 +9,14 @@
 #define VIT_TAIL 6u              // K-1 tail steps
 #define VIT_SORT_BINS (VIT_MAX_FRAMEBITS / 8u + 1u)  // counting-sort keys framebits/8
 
+// renorm_ge (all decoder launchers): the renormalisation test on state 0.  false = `> 150`, the reference's C decoders
+// (deconvolve.cpp:399,408; build configuration Rel_cpp); true = `>= 150`, its MASM decoders (decon_avx2.asm:97,114
+// `cmp sil,150 ; jb mainloop`; Rel_asm, the configuration QIRX ships).  The two differ on hard-decision input from a
+// poor channel, where path metrics reach the 0 / 255 clamps.
 // Wave-per-frame kernel (lane = trellis state); any even framebits <= 9216.
 hipError_t vit_launch_wave(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_desc* d_desc,
                            uint32_t framebits, uint32_t max_framebits, int64_t nframes,
-                           hipStream_t stream);
+                           hipStream_t stream, bool renorm_ge);
 // Packed kernel: 4 frames per wavefront, 2 states x 2 frames per lane register.
 // Every even framebits <= 9216 (frames longer than 778 bits spill their history through HBM).
 bool vit_pk_supported(uint32_t max_framebits);
@@ -20,14 +24,14 @@ bool vit_pk_supported(uint32_t max_framebits);
 // then counts symbols); the narrowing to the low byte is fused into the kernel's pre-pass.
 hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, const vit_frame_desc* d_desc,
                          uint32_t framebits, uint32_t max_framebits, int64_t nframes,
-                         hipStream_t stream);
+                         hipStream_t stream, bool renorm_ge);
 // Latency kernel: one frame per wavefront, one path metric per lane, DPP partner fetches (small launches).
 #define VIT_LAT_MAX_FRAMES 2048  // auto selection: up to two waves per SIMD; beyond that the packed kernel's throughput wins
 // done_flag (optional, nframes == 1 only): a word in host-visible memory that receives done_seq, with system-scope
 // release semantics, after the frame's last output byte.
 hipError_t vit_launch_lat(const void* d_symbols, bool sym32, uint8_t* d_out, const vit_frame_desc* d_desc,
                           uint32_t framebits, uint32_t max_framebits, int64_t nframes,
-                          hipStream_t stream, uint32_t* done_flag = nullptr, uint32_t done_seq = 0);
+                          hipStream_t stream, uint32_t* done_flag, uint32_t done_seq, bool renorm_ge);
 // frames the latency kernel can keep resident at one wave per SIMD or so for this frame length (LDS-limited)
 int64_t vit_lat_capacity(uint32_t max_framebits, int dev);
 // Length-sorted (longest first) copy of a device descriptor table; d_bins = 2*VIT_SORT_BINS words of scratch.

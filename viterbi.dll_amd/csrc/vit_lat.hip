@@ -109,7 +109,7 @@ DEV void push_decisions(u32& acc, u64 d, u32 after = 0) {
 // chain behind a VALU -> SGPR -> VALU hand-off: the mask (pd) of step t is therefore consumed one step LATER,
 // between the adds and the compare of step t+1 (PENDING = there is one).
 template <int RHO, bool PENDING>
-DEV void step(u32& m, u32& acc, u64& pd, const char* tabrow, u32 toff, u32 lane) {
+DEV void step(u32& m, u32& acc, u64& pd, const char* tabrow, u32 toff, u32 lane, u32 thr) {
     constexpr int J = (5 - RHO + 6) % 6;
     const uint2 X = *reinterpret_cast<const uint2*>(tabrow + toff);  // x: M, y: 63 - M
     const u32 om = m + X.x;                 // candidates, NOT yet clamped (<= 255 + 63)
@@ -120,9 +120,10 @@ DEV void step(u32& m, u32& acc, u64& pd, const char* tabrow, u32 toff, u32 lane)
     const u32 hi = ((lane >> J) & 1u) ? om : pm;         // the candidate from state i+32 (v_cndmask, constant lane mask)
     pd = __builtin_amdgcn_ballot_w64(min(hi, 255u) == n);
     if constexpr (RHO & 1) {
-        // Renormalize256 (deconvolve.cpp:407-412): state 0 = lane 0
+        // Renormalize256 (deconvolve.cpp:407-412: state 0 > 150; the MASM twins test >= 150, decon_avx2.asm:97,114:
+        // thr = 150 or 149): state 0 = lane 0
         // (compare in every lane, take lane 0's bit: one hop shorter than v_readfirstlane + scalar compare)
-        const u64 gt = __builtin_amdgcn_ballot_w64(n > 150u);
+        const u64 gt = __builtin_amdgcn_ballot_w64(n > thr);
         u32 K;
         asm("s_bitcmp1_b32 %1, 0\n\ts_cselect_b32 %0, 63, 0" : "=s"(K) : "s"((u32)gt) : "scc");
         m = __builtin_elementwise_sub_sat(n, K);  // psubusb
@@ -135,15 +136,15 @@ DEV void step(u32& m, u32& acc, u64& pd, const char* tabrow, u32 toff, u32 lane)
 // dependent chain), history word stored once the decisions of every 32nd step are in.
 template <int S>
 struct ChunkSteps {
-    static DEV void run(u32& m, u32& acc, u64& pd, const char* tab, const u32 (&toff)[6], u32 lane, u32* decw) {
-        step<S % 6, (S > 0)>(m, acc, pd, tab + S * 64, toff[S % 6], lane);
+    static DEV void run(u32& m, u32& acc, u64& pd, const char* tab, const u32 (&toff)[6], u32 lane, u32* decw, u32 thr) {
+        step<S % 6, (S > 0)>(m, acc, pd, tab + S * 64, toff[S % 6], lane, thr);
         if constexpr (S > 0 && S % 32 == 0) decw[(S / 32 - 1) * 64] = acc;  // steps S-32 .. S-1; step t at bit 31 - (t & 31)
-        ChunkSteps<S + 1>::run(m, acc, pd, tab, toff, lane, decw);
+        ChunkSteps<S + 1>::run(m, acc, pd, tab, toff, lane, decw, thr);
     }
 };
 template <>
 struct ChunkSteps<(int)CHUNK> {
-    static DEV void run(u32&, u32& acc, u64& pd, const char*, const u32 (&)[6], u32, u32* decw) {
+    static DEV void run(u32&, u32& acc, u64& pd, const char*, const u32 (&)[6], u32, u32* decw, u32) {
         push_decisions(acc, pd);  // the chunk's last step
         decw[(CHUNK / 32u - 1u) * 64u] = acc;
     }
@@ -153,7 +154,7 @@ template <bool SYM32>
 __global__ __launch_bounds__(64) void vit_lat_kernel(const uint8_t* __restrict__ sym, uint8_t* __restrict__ out,
                                                      const vit_frame_desc* __restrict__ desc, u32 framebits_uniform,
                                                      u32 max_framebits, long long nframes, LatLayout lay,
-                                                     u32* done_flag, u32 done_seq) {
+                                                     u32* done_flag, u32 done_seq, u32 renorm_thr) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     u32* symb = reinterpret_cast<u32*>(lds + lay.sym_off);
     char* tab = lds + lay.tab_off;
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(64) void vit_lat_kernel(const uint8_t* __restrict__
             if (lane < CHUNK - 64u) prepass_row(ch * CHUNK, 64u + lane);
             __syncthreads();
             u64 pd = 0;
-            ChunkSteps<0>::run(m, acc, pd, tab, toff, lane, dec + ch * (CHUNK / 32u) * 64u + lane);
+            ChunkSteps<0>::run(m, acc, pd, tab, toff, lane, dec + ch * (CHUNK / 32u) * 64u + lane, renorm_thr);
         }
         __syncthreads();
 
@@ -357,7 +358,8 @@ int64_t vit_lat_capacity(uint32_t max_framebits, int dev) {
 
 hipError_t vit_launch_lat(const void* d_symbols, bool sym32, uint8_t* d_out, const vit_frame_desc* d_desc,
                           uint32_t framebits, uint32_t max_framebits, int64_t nframes, hipStream_t stream,
-                          uint32_t* done_flag, uint32_t done_seq) {
+                          uint32_t* done_flag, uint32_t done_seq, bool renorm_ge) {
+    const u32 thr = renorm_ge ? 149u : 150u;  // the kernels test `> thr`
     if (done_flag && nframes != 1) return hipErrorInvalidValue;  // one workgroup writes the flag
     if (nframes <= 0) return hipSuccess;
     if (sym32 && (reinterpret_cast<uintptr_t>(d_symbols) & 15u)) return hipErrorInvalidValue;  // uint4 loads
@@ -373,9 +375,9 @@ hipError_t vit_launch_lat(const void* d_symbols, bool sym32, uint8_t* d_out, con
     const uint8_t* d_sym = static_cast<const uint8_t*>(d_symbols);
     if (sym32)
         hipLaunchKernelGGL(vit_lat_kernel<true>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out, d_desc,
-                           framebits, max_framebits, (long long)nframes, lay, done_flag, done_seq);
+                           framebits, max_framebits, (long long)nframes, lay, done_flag, done_seq, thr);
     else
         hipLaunchKernelGGL(vit_lat_kernel<false>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out, d_desc,
-                           framebits, max_framebits, (long long)nframes, lay, done_flag, done_seq);
+                           framebits, max_framebits, (long long)nframes, lay, done_flag, done_seq, thr);
     return hipGetLastError();
 }

@@ -152,7 +152,13 @@ DEV void exchange(u32& A, u32& B, u32 N0, u32 N1, u32 lane) {
 
 struct Consts {
     u32 hi;  // 0xFF00FF00 in a VGPR
+    u32 rc;  // renormalisation test constant (wave-uniform, SGPR), see pk_renorm_const()
 };
+// Renormalize256's threshold test as ONE 32-bit add on z = m + 0xFF00 per half: z + c has bit 15 set iff m exceeds the
+// threshold.  The low half always carries out (0xFF00 + 0x80xx >= 2^16), so the high half's constant is one less.
+//   C twins,    deconvolve.cpp:408  `> 150`  (m >= 151): c = 0x8069 -> 0x80688069
+//   MASM twins, decon_avx2.asm:97,114 `cmp sil,150 ; jb` = `>= 150`: c = 0x806A -> 0x8069806A
+__host__ __device__ inline u32 pk_renorm_const(bool ge) { return ge ? 0x8069806Au : 0x80688069u; }
 
 // One trellis step for 4 frames (deconvolve.cpp:352-374 in packed u16 form).
 template <int RHO, int J, bool HIST>
@@ -183,9 +189,9 @@ DEV void acs_step(u32& A, u32& B, u32& acc0, u32& acc1, u32 mt, u32 lane, const 
         acc1 = bfi(mask, W(x23), acc1);
     }
     if constexpr (ODD) {
-        // Renormalize256: state 0 (lane 0 of the pair, register N0) > 150 -> psubusb 63.
-        // z = m + 0xFF00 per half.  z + 0x8069 has bit 15 set iff m >= 151; done as ONE 32-bit add:
-        // the low half always carries out (0xFF00 + 0x8069 >= 2^16), so the high constant is 0x8068.
+        // Renormalize256: state 0 (lane 0 of the pair, register N0) > 150 (or >= 150, the MASM decoders' test) ->
+        // psubusb 63.  z = m + 0xFF00 per half.  z + 0x8069 has bit 15 set iff m >= 151; done as ONE 32-bit add:
+        // the low half always carries out (0xFF00 + 0x8069 >= 2^16), so the high constant is 0x8068 (C.rc).
         // The subtrahend is per frame, i.e. the same for every lane and both registers of a pair, so it
         // commutes with the lane exchange: the broadcast and the exchange are issued together and
         // the subtraction lands on the exchanged registers (one LDS latency instead of two in a row).
@@ -199,7 +205,7 @@ DEV void acs_step(u32& A, u32& B, u32& acc0, u32& acc1, u32 mt, u32 lane, const 
         // v_add_u32 (2.7 cycles; bit 15 of each half := m >= 151), v_pk_ashrrev_i16 15, v_and_or_b32
         u32 K;
         {
-            const u32 w = z + 0x80688069u;
+            const u32 w = z + C.rc;
             asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]\n\t"
                 "v_and_or_b32 %0, %0, %2, %3"
                 : "=&v"(K)
@@ -212,9 +218,9 @@ DEV void acs_step(u32& A, u32& B, u32& acc0, u32& acc1, u32 mt, u32 lane, const 
             "v_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]\n\t"
             "v_and_or_b32 %0, %0, %3, %4"
             : "=&v"(K)
-            : "v"(z), "s"(0x80698069u), "s"(0x003F003Fu), "v"(C.hi));
+            : "v"(z), "s"(C.rc + 0x00010000u), "s"(0x003F003Fu), "v"(C.hi));
 #else
-        const u32 w = z + 0x80688069u;
+        const u32 w = z + C.rc;
         const u32 t = (w >> 15) & 0x00010001u;
         const u32 K = t * 63u + C.hi;  // v_mad_u32_u24: 0xFF00 + {0,63} per half
 #endif
@@ -522,7 +528,7 @@ template <bool SYM32>
 __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict__ sym, uint8_t* __restrict__ out,
                                                         const vit_frame_desc* __restrict__ desc, u32 framebits_uniform,
                                                         long long nframes, PkLayout lay, u32 vmax,
-                                                        const unsigned* __restrict__ split_gate) {
+                                                        const unsigned* __restrict__ split_gate, u32 renorm_c) {
     // second launch behind the long-frame kernel on a length-sorted table: runs only if that kernel left the short
     // groups to it (same test there, see vit_launch_pk)
     if (split_gate && (unsigned long long)*split_gate * PK_SPLIT_DEN >= (unsigned long long)nframes) return;
@@ -592,6 +598,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
     }
     Consts C;
     C.hi = HI;
+    C.rc = renorm_c;
     asm volatile("" : "+v"(C.hi));  // keep it in a VGPR
     // ---- pre-pass lane constants: lane = (tau = lane>>1, pair pp = lane&1) ----
     const u32 tau = lane >> 1, pp = lane & 1u;
@@ -715,7 +722,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
                                                              u32 framebits_uniform, long long nframes, PkLayout lay,
                                                              uint2* spill, u32 spill_blocks, unsigned* counter,
                                                              u32 ngroups, u32 short_max,
-                                                             const unsigned* __restrict__ split_gate) {
+                                                             const unsigned* __restrict__ split_gate, u32 renorm_c) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* dec = lds;                  // 16 blocks; the 17th (last) lands on the dead table
     char* tab = lds + lay.dec_bytes;  // [tau][pair][c] -> M; after the ACS: last block, scratch, image
@@ -739,6 +746,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
     }
     Consts C;
     C.hi = HI;
+    C.rc = renorm_c;
     asm volatile("" : "+v"(C.hi));
     const u32 tau = lane >> 1, pp = lane & 1u;
     u32 sel[4];
@@ -777,9 +785,15 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
             maxfb = fbits[k] > maxfb ? fbits[k] : maxfb;
         }
         if (maxfb == 0) continue;
-        // length-sorted mixed table: from the first group that fits the single-segment kernel on, the rest is
-        // that kernel's (it keeps two thirds of the history in VGPRs instead of spilling it)
-        if (maxfb <= short_max && split) break;
+        // length-sorted mixed table: the groups that fit the single-segment kernel are that kernel's (it keeps two
+        // thirds of the history in VGPRs instead of spilling it).  The table is ordered by the sort's 8-bit-wide bins
+        // only: bin 98 holds 778-bit frames (short) next to 780/782/784-bit ones (long) in no particular order, so a
+        // short group inside that bin is skipped, not taken as the end; from the first group of the bins below
+        // (maxfb <= 776) on, every later group is short as well.
+        if (split && maxfb <= short_max) {
+            if (maxfb <= (short_max & ~7u)) break;
+            continue;
+        }
         const u32 nblk = (maxfb + VIT_TAIL + 15u) >> 4;
         const u32 G = nblk > LONG_LDS_BLOCKS ? nblk - LONG_LDS_BLOCKS : 0u;  // spilled blocks (<= spill_blocks)
         const u32 T_max = maxfb + VIT_TAIL;
@@ -930,7 +944,8 @@ bool sort_enabled() {
 }
 
 hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, const vit_frame_desc* d_desc,
-                         uint32_t framebits, uint32_t max_framebits, int64_t nframes, hipStream_t stream) {
+                         uint32_t framebits, uint32_t max_framebits, int64_t nframes, hipStream_t stream, bool renorm_ge) {
+    const u32 rc = pk_renorm_const(renorm_ge);
     const uint8_t* d_sym = static_cast<const uint8_t*>(d_symbols);
     if (sym32 && (reinterpret_cast<uintptr_t>(d_symbols) & 15u)) return hipErrorInvalidValue;  // uint4 loads
     if (nframes <= 0) return hipSuccess;
@@ -967,10 +982,10 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
     if (!need_counter && !sort) {
         if (sym32)
             hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
-                               d_desc, framebits, (long long)nframes, lay, lay.maxfb, (const unsigned*)nullptr);
+                               d_desc, framebits, (long long)nframes, lay, lay.maxfb, (const unsigned*)nullptr, rc);
         else
             hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
-                               d_desc, framebits, (long long)nframes, lay, lay.maxfb, (const unsigned*)nullptr);
+                               d_desc, framebits, (long long)nframes, lay, lay.maxfb, (const unsigned*)nullptr, rc);
         return hipGetLastError();
     }
     const u32 spill_blocks = is_long ? nblk - LONG_LDS_BLOCKS : 0u;
@@ -1026,19 +1041,19 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
         if (sym32)
             hipLaunchKernelGGL(vit_pk_long_kernel<true>, dim3((unsigned)grid), dim3(64), lay.total, ls, d_sym, d_out,
                                d_desc, framebits, (long long)nframes, lay, spill, spill_blocks, counter, (u32)groups,
-                               short_max, gate);
+                               short_max, gate, rc);
         else
             hipLaunchKernelGGL(vit_pk_long_kernel<false>, dim3((unsigned)grid), dim3(64), lay.total, ls, d_sym, d_out,
                                d_desc, framebits, (long long)nframes, lay, spill, spill_blocks, counter, (u32)groups,
-                               short_max, gate);
+                               short_max, gate, rc);
         if (short_max && (e = hipGetLastError()) == hipSuccess) {
             const PkLayout lsh = pk_layout(PK_SHORT_MAX);
             if (sym32)
                 hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)groups), dim3(64), lsh.total, stream, d_sym, d_out,
-                                   d_desc, framebits, (long long)nframes, lsh, max_framebits, gate);
+                                   d_desc, framebits, (long long)nframes, lsh, max_framebits, gate, rc);
             else
                 hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)groups), dim3(64), lsh.total, stream, d_sym, d_out,
-                                   d_desc, framebits, (long long)nframes, lsh, max_framebits, gate);
+                                   d_desc, framebits, (long long)nframes, lsh, max_framebits, gate, rc);
             // join: whatever the caller enqueues next waits for both kernels
             if ((e = hipGetLastError()) != hipSuccess) return e;
             if ((e = hipEventRecord(sc.ev_join, sc.side)) != hipSuccess) return e;
@@ -1046,10 +1061,10 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
         }
     } else if (sym32) {
         hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
-                           d_desc, framebits, (long long)nframes, lay, lay.maxfb, (const unsigned*)nullptr);
+                           d_desc, framebits, (long long)nframes, lay, lay.maxfb, (const unsigned*)nullptr, rc);
     } else {
         hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
-                           d_desc, framebits, (long long)nframes, lay, lay.maxfb, (const unsigned*)nullptr);
+                           d_desc, framebits, (long long)nframes, lay, lay.maxfb, (const unsigned*)nullptr, rc);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     return hipEventRecord(sc.ev, stream);

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(64) void vit_wave_kernel(const uint8_t* __restrict_
                                                       uint8_t* __restrict__ out,
                                                       const vit_frame_desc* __restrict__ desc,
                                                       uint32_t framebits_uniform, uint32_t max_framebits,
-                                                      long long nframes) {
+                                                      long long nframes, uint32_t renorm_thr) {
     extern __shared__ unsigned long long dec[];  // one 64-bit decision word per step
     const uint32_t lane = threadIdx.x;
     // Branch mask of this lane's butterfly i = lane>>1: byte j = 0xFF iff
@@ -69,9 +69,9 @@ __global__ __launch_bounds__(64) void vit_wave_kernel(const uint8_t* __restrict_
             m = d ? cb : ca;
             const unsigned long long dw = __ballot(d);
             if (lane == 0) dec[t] = dw;
-            if (t & 1u) {  // Renormalize256 after every second step, state 0 only, > 150
+            if (t & 1u) {  // Renormalize256 after every second step, state 0 only, > 150 (MASM twins: >= 150, thr = 149)
                 const uint32_t m0 = __builtin_amdgcn_readfirstlane(m);
-                if (m0 > 150u) m = m > 63u ? m - 63u : 0u;  // psubusb
+                if (m0 > renorm_thr) m = m > 63u ? m - 63u : 0u;  // psubusb
             }
         }
         __syncthreads();
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void vit_pack_kernel(const uint32_t* __restric
 
 hipError_t vit_launch_wave(const uint8_t* d_sym, uint8_t* d_out, const vit_frame_desc* d_desc,
                            uint32_t framebits, uint32_t max_framebits, int64_t nframes,
-                           hipStream_t stream) {
+                           hipStream_t stream, bool renorm_ge) {
     if (nframes <= 0) return hipSuccess;
     const size_t lds = (size_t)(max_framebits + VIT_TAIL) * 8u;
     static uint64_t optin_done = 0;
@@ -118,7 +118,7 @@ hipError_t vit_launch_wave(const uint8_t* d_sym, uint8_t* d_out, const vit_frame
     if ((e = vit_optin_dynamic_lds(ks, 1, 80 * 1024, dev, &optin_done)) != hipSuccess) return e;
     const long long grid = nframes < (1 << 20) ? nframes : (1 << 20);
     hipLaunchKernelGGL(vit_wave_kernel, dim3((unsigned)grid), dim3(64), lds, stream, d_sym, d_out, d_desc,
-                       framebits, max_framebits, (long long)nframes);
+                       framebits, max_framebits, (long long)nframes, renorm_ge ? 149u : 150u);
     return hipGetLastError();
 }
 

@@ -123,6 +123,13 @@ int vit_decode_batch_dev_u32(const uint32_t *d_symbols_u32, uint8_t *d_decoded,
 int vit_decode_varlen_dev(const uint8_t *d_symbols_u8, uint8_t *d_decoded,
                           const vit_frame_desc *d_desc, int64_t nframes,
                           uint32_t max_framebits, void *stream);
+/* Same, for a table the caller does not trust: sym_bytes / out_bytes are the sizes of the two buffers, and a
+ * descriptor whose 4*(framebits+6) symbol bytes or (framebits+7)/8 output bytes would lie (even partly) outside them
+ * is skipped like the other invalid ones (checked on the device, in a copy of the table; nothing is read or written
+ * for it).  vit_decode_varlen_dev itself takes no sizes: there a bad offset is an out-of-bounds device access. */
+int vit_decode_varlen_dev_checked(const uint8_t *d_symbols_u8, uint64_t sym_bytes, uint8_t *d_decoded,
+                                  uint64_t out_bytes, const vit_frame_desc *d_desc, int64_t nframes,
+                                  uint32_t max_framebits, void *stream);
 /* Host helper: reorder a HOST array of descriptors by framebits (longest first, stable) before
  * uploading it.  Optional since the device-side sort above; kept for callers that build tables of
  * fewer than 16 frames or want a deterministic order.  Every descriptor carries its own offsets,

@@ -35,6 +35,22 @@ def test_bare_command_spawns_two_ranks(mode, extra):
         assert r["routing_ok"] is True
 
 
+def test_n_gt_1_record_describes_itself():
+    """the default N > 1 run (shard mode) also pushes the same frames through the one-root scatter pipeline and prints
+    both in ONE JSON line: `value` = per-GPU ingestion, `scatter` = rank 0 owns the stream, with the split it used
+    and the bound DESIGN.md (e) predicts; gloo rehearsal, 3 ranks"""
+    r = _run(["--gpus", "3", "--frames", "64"])
+    assert r["n_gpus"] == 3 and r["mode"] == "shard" and r["backend"] == "gloo" and r["rccl_ranks"] == 0
+    assert r["xgmi_bytes_in_timed_region"] == 0
+    sc = r["scatter"]
+    assert sc["frames"] == 3 * 64 and sc["every_frame_matches_the_shard_decode"] is True and sc["value"] > 0
+    assert sc["chunk_frames"] >= 4 and sc["root_frames"] == 2 * sc["chunk_frames"]  # the rehearsal pretends D = 2 L
+    assert sc["predicted"]["speedup_vs_1gpu_bound"] == 2.0 and "speedup_vs_1gpu_measured" in sc
+    # the leg can be switched off, and the explicit scatter mode does not nest it
+    assert "scatter" not in _run(["--gpus", "2", "--no-scatter-leg"])
+    assert "scatter" not in _run(["--gpus", "2", "--mode", "scatter", "--chunk-frames", "10"])
+
+
 def test_three_ranks_and_forced_spawn_of_one():
     assert _run(["--gpus", "3", "--mode", "scatter", "--chunk-frames", "7"])["n_gpus"] == 3
     r = _run(["--gpus", "1", "--spawn"])

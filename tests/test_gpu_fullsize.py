@@ -17,32 +17,46 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_golden_fixtures_on_gpu(V, torch_cuda):
-    """the HIP path against the COMMITTED bytes of tests/golden/golden.json - no oracle involved"""
+    """the HIP path against the COMMITTED bytes of tests/golden/golden.json - no oracle involved.  Both renormalise
+    comparators: `out_hex` (> 150, deconvolve.cpp:407-412) and `out_ge_hex` (>= 150, decon_avx2.asm:94-118)."""
+    import zlib
     torch = torch_cuda
     g = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
-    assert len(g["decode"]) >= 8 and len(g["rs"]) >= 4
-    for case in g["decode"]:
-        fb = case["framebits"]
-        sym = np.frombuffer(base64.b64decode(case["sym_b64"]), np.uint8)
-        want = np.frombuffer(bytes.fromhex(case["out_hex"]), np.uint8)
-        assert sym.size == 4 * (fb + 6)
-        for kernel in (1, 2, 3):
-            old = V.set_kernel(kernel)
-            try:
-                d_out = torch.zeros((fb + 7) // 8, dtype=torch.uint8, device="cuda")
-                V.decode_batch_dev(torch.from_numpy(sym.copy()).cuda(), d_out, fb, 1)
-                torch.cuda.synchronize()
-            finally:
-                V.set_kernel(old)
-            assert np.array_equal(d_out.cpu().numpy(), want), (fb, case["kind"], kernel)
-        rc, got = V.deconvolve(fb, sym.astype(np.uint32))  # the drop-in export, reference ABI
-        assert rc == 0 and np.array_equal(got, want)
+    assert len(g["decode"]) >= 17 and len(g["rs"]) >= 10
+    try:
+        for case in g["decode"]:
+            fb = case["framebits"]
+            sym = np.frombuffer(zlib.decompress(base64.b64decode(case["sym_zb64"])), np.uint8)
+            assert sym.size == 4 * (fb + 6)
+            for ge, key in ((0, "out_hex"), (1, "out_ge_hex")):
+                want = np.frombuffer(bytes.fromhex(case[key]), np.uint8)
+                V.set_renorm_ge(ge)
+                for kernel in (1, 2, 3):
+                    old = V.set_kernel(kernel)
+                    try:
+                        d_out = torch.zeros((fb + 7) // 8, dtype=torch.uint8, device="cuda")
+                        V.decode_batch_dev(torch.from_numpy(sym.copy()).cuda(), d_out, fb, 1)
+                        torch.cuda.synchronize()
+                    finally:
+                        V.set_kernel(old)
+                    assert np.array_equal(d_out.cpu().numpy(), want), (fb, case["kind"], kernel, key)
+                rc, got = V.deconvolve(fb, sym.astype(np.uint32))  # the drop-in export, reference ABI
+                assert rc == 0 and np.array_equal(got, want), (fb, case["kind"], key)
+    finally:
+        V.set_renorm_ge(0)
     for case in g["rs"]:
         rs = case["rsdims"]
         p = np.frombuffer(bytes.fromhex(case["p_hex"]), np.uint8)
         want = np.frombuffer(bytes.fromhex(case["out_hex"]), np.uint8)
         rc, out = V.RScheckSuperframe(p.copy(), 0, rs, np.full(110 * rs, 0xA5, np.uint8))
-        assert rc == case["ret"] and np.array_equal(out, want)
+        assert rc == case["ret"] and np.array_equal(out, want), case["note"]
+        # the batched entry point on the same block, between two other superframes
+        blk = np.stack([np.roll(p, 7), p, p[::-1]])
+        d_out = torch.full((3, 110 * rs), 0xA5, dtype=torch.uint8, device="cuda")
+        d_ret = torch.zeros(3, dtype=torch.int32, device="cuda")
+        V.rs_batch_dev(torch.from_numpy(blk.copy()).cuda(), d_out, d_ret, rs, 3)
+        torch.cuda.synchronize()
+        assert int(d_ret[1]) == case["ret"] and np.array_equal(d_out[1].cpu().numpy(), want), case["note"]
 
 
 def test_config3_full_size_mixed_lengths(V, O, torch_cuda):

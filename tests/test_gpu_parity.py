@@ -405,6 +405,42 @@ def test_split_table_handover_inside_a_sort_bin(V, O, torch_cuda, kernel):
     assert not bad, "(framebits, frames that differ, first index): %s" % bad
 
 
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3])
+def test_varlen_checked_skips_descriptors_outside_the_buffers(V, O, torch_cuda, kernel):
+    """vit_decode_varlen_dev_checked: a descriptor whose symbols or output bytes reach outside the two buffers (far
+    outside, or by one byte) is skipped on the device like the other invalid ones - nothing read, nothing written;
+    the rest of the table decodes bit-exact.  Table sizes below and above the sort threshold (16)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(21)
+    for nfr in (9, 700):
+        fbs = [int(x) for x in 8 * rng.integers(1, 130, nfr)] + [3072, 768]
+        desc, sym_bytes, out_bytes = V.make_descs(fbs)
+        sym = O.uniform_symbols(sym_bytes, seed=nfr)
+        want = np.full(out_bytes, 0x5A, np.uint8)
+        bad = {1: ("sym_offset", 1 << 40), 3: ("out_offset", 1 << 41),
+               5: ("sym_offset", sym_bytes - O.sym_len(fbs[5]) + 4),   # the last dword lies outside
+               6: ("out_offset", out_bytes - fbs[6] // 8 + 1),         # the last byte lies outside
+               len(fbs) - 1: ("sym_offset", (1 << 64) - 4)}            # offset + size wraps around
+        for i, (fb, d) in enumerate(zip(fbs, desc)):
+            so, oo = int(d["sym_offset"]), int(d["out_offset"])
+            if i not in bad:
+                want[oo:oo + fb // 8] = O.decode_batch(fb, sym[so:so + O.sym_len(fb)])[0]
+        for i, (field, val) in bad.items():
+            desc[field][i] = val
+        # the last descriptor of the ORIGINAL layout ends exactly at the end of both buffers: it must be decoded
+        assert len(fbs) - 2 not in bad
+        d_desc = torch.from_numpy(desc.view(np.uint8)).cuda()
+        d_out = torch.full((out_bytes,), 0x5A, dtype=torch.uint8, device="cuda")
+        old = V.set_kernel(kernel)
+        try:
+            V.decode_varlen_dev_checked(torch.from_numpy(sym).cuda(), d_out, d_desc, len(fbs), 3072)
+            torch.cuda.synchronize()
+        finally:
+            V.set_kernel(old)
+        assert np.array_equal(d_out.cpu().numpy(), want), (kernel, nfr)
+        assert np.array_equal(d_desc.cpu().numpy(), desc.view(np.uint8))  # the caller's table is not modified
+
+
 def test_long_frames_from_threads_and_streams(V, O, torch_cuda):
     """the long-frame kernel's spill/sort scratch is per calling thread and its reuse is ordered by an
     event: two threads, each alternating between two streams with different frame lengths, back to back"""

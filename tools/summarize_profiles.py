@@ -59,7 +59,11 @@ if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
     traffic = fetch + write
     lines.append("\nHBM traffic per launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 = %.4g + %.4g = %.4g B; algorithmic %.4g B; ratio %.3f\n"
                  % (fetch, write, traffic, alg, traffic / alg))
-    pmc_json = {"round": tag, "kernel": KERNEL, "source": "tools/collect_profiles.sh %s: rocprofv3 --pmc passes of `python bench.py --no-cpu`" % tag,
+    pmc_json = {"round": tag, "kernel": KERNEL,
+                # the configuration these counters belong to: bench.py attaches them only to a run of the same one
+                "config": {"frames_per_gpu": bench["config"].get("frames_per_gpu", 65536), "kernel": bench["config"].get("kernel", 0),
+                           "mode": bench.get("mode", "shard"), "renorm_ge": bench["config"].get("renorm_ge", 0)},
+                "source": "tools/collect_profiles.sh %s: rocprofv3 --pmc passes of `python bench.py --no-cpu`" % tag,
                 "hbm_bytes_per_launch": int(traffic), "fetch_bytes_corrected": int(fetch),
                 "write_bytes": int(write), "algorithmic_bytes_per_launch": alg,
                 "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units; "

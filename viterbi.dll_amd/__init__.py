@@ -22,7 +22,7 @@ EXPORTS = [
     "deconvolve", "initialize", "RScheckSuperframe", "RSCheckSuperframe", "GetCPUCaps", "WakeUpYMM",
     "vit_last_error", "vit_device_count", "vit_set_kernel", "vit_set_renorm_ge", "vit_set_batch_window_us", "vit_set_batch_min_callers",
     "vit_decode_batch_dev",
-    "vit_decode_batch_dev_u32", "vit_decode_varlen_dev", "vit_pack_symbols_dev", "vit_sort_descs",
+    "vit_decode_batch_dev_u32", "vit_decode_varlen_dev", "vit_decode_varlen_dev_checked", "vit_pack_symbols_dev", "vit_sort_descs",
     "vit_decode_batch_host", "vit_rs_batch_dev", "vit_rs_batch_host", "vit_dabplus_superframes_dev",
     "vit_decode_stream_multi",
 ]
@@ -76,6 +76,7 @@ def lib():
         L.vit_decode_batch_dev.argtypes = [vp, vp, C.c_uint32, C.c_int64, vp]
         L.vit_decode_batch_dev_u32.argtypes = [vp, vp, C.c_uint32, C.c_int64, vp]
         L.vit_decode_varlen_dev.argtypes = [vp, vp, vp, C.c_int64, C.c_uint32, vp]
+        L.vit_decode_varlen_dev_checked.argtypes = [vp, C.c_uint64, vp, C.c_uint64, vp, C.c_int64, C.c_uint32, vp]
         L.vit_pack_symbols_dev.argtypes = [vp, vp, C.c_int64, vp]
         L.vit_sort_descs.argtypes = [vp, C.c_int64]
         L.vit_sort_descs.restype = None
@@ -203,6 +204,15 @@ def decode_varlen_dev(d_symbols_u8, d_out, d_desc, nframes, max_framebits, strea
     _check(lib().vit_decode_varlen_dev(C.c_void_p(d_symbols_u8.data_ptr()), C.c_void_p(d_out.data_ptr()),
                                        C.c_void_p(d_desc.data_ptr()), nframes, max_framebits,
                                        _stream_ptr(stream)), "vit_decode_varlen_dev")
+
+
+def decode_varlen_dev_checked(d_symbols_u8, d_out, d_desc, nframes, max_framebits, stream=None, sym_bytes=None,
+                              out_bytes=None):
+    """descriptors that reach outside the two buffers (sizes default to the tensors' sizes) are skipped on the device"""
+    _check(lib().vit_decode_varlen_dev_checked(
+        C.c_void_p(d_symbols_u8.data_ptr()), d_symbols_u8.numel() if sym_bytes is None else sym_bytes,
+        C.c_void_p(d_out.data_ptr()), d_out.numel() if out_bytes is None else out_bytes,
+        C.c_void_p(d_desc.data_ptr()), nframes, max_framebits, _stream_ptr(stream)), "vit_decode_varlen_dev_checked")
 
 
 def sort_descs(desc):

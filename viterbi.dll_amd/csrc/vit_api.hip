@@ -117,7 +117,7 @@ void probe_devices() {
 void ensure_init() { std::call_once(g_once, probe_devices); }
 
 // ---- per-thread context: stream + staging (README.md:56: callers are threads) ----
-// Everything in it belongs to ONE device (`dev`); a thread that comes back with another device gets a fresh one.
+// Everything in it belongs to ONE device (`dev`).
 struct ThreadCtx {
     int dev = -1;
     hipStream_t stream = nullptr;
@@ -127,7 +127,8 @@ struct ThreadCtx {
     void* d_sym8 = nullptr;  size_t d8_cap = 0;  // packed symbols
     void* d_out = nullptr;   size_t dout_cap = 0;
     void* d_ret = nullptr;   size_t dret_cap = 0;
-    hipEvent_t scratch_ev = nullptr;  // last use of d_sym8 by a *_dev call on a caller-owned stream
+    void* d_desc = nullptr;  size_t ddesc_cap = 0;  // bounds-checked descriptor copy (vit_decode_varlen_dev_checked)
+    hipEvent_t scratch_ev = nullptr;  // last use of d_sym8 / d_desc by a *_dev call on a caller-owned stream
     uint32_t seq = 0;                 // completion sequence number of the single-call latency path
     bool ready = false;
     void release() {
@@ -138,13 +139,22 @@ struct ThreadCtx {
         if (d_sym8) (void)hipFree(d_sym8);
         if (d_out) (void)hipFree(d_out);
         if (d_ret) (void)hipFree(d_ret);
+        if (d_desc) (void)hipFree(d_desc);
         if (scratch_ev) (void)hipEventDestroy(scratch_ev);
         if (stream) (void)hipStreamDestroy(stream);
         *this = ThreadCtx();
     }
     ~ThreadCtx() { release(); }
 };
-thread_local ThreadCtx t_ctx;
+// One context per (thread, device): a thread that alternates between devices (vit_decode_stream_multi drives all its
+// ranks from one host thread) keeps every device's stream and buffers instead of freeing and re-creating them.
+constexpr int VIT_MAX_DEVS = 64;
+struct ThreadCtxs {
+    ThreadCtx by_dev[VIT_MAX_DEVS];
+};
+thread_local ThreadCtxs t_ctxs;
+thread_local ThreadCtx* t_ctx_cur = &t_ctxs.by_dev[0];  // set by ctx_prepare()
+#define t_ctx (*t_ctx_cur)
 
 #define HIPCHK(call)                                                                       \
     do {                                                                                   \
@@ -167,10 +177,11 @@ int hip_device_ready() {
 // Makes the calling thread's context usable on device `dev`, which must be the CURRENT device (the exported
 // entry points hold a VitDeviceGuard, so the caller's own current device is restored when they return).
 int ctx_prepare(int dev) {
-    if (t_ctx.ready && t_ctx.dev != dev) {
-        if (t_ctx.stream) (void)hipStreamSynchronize(t_ctx.stream);
-        t_ctx.release();
+    if (dev < 0 || dev >= VIT_MAX_DEVS) {
+        set_err("HIP device ordinal %d out of range", dev);
+        return VIT_ERR_ARG;
     }
+    t_ctx_cur = &t_ctxs.by_dev[dev];
     if (!t_ctx.ready) {
         HIPCHK(hipStreamCreateWithFlags(&t_ctx.stream, hipStreamNonBlocking));
         t_ctx.dev = dev;
@@ -551,6 +562,34 @@ int vit_decode_varlen_dev(const uint8_t* d_symbols_u8, uint8_t* d_decoded, const
     return launch_decode(decode_mode(), d_symbols_u8, d_decoded, d_desc, 0, max_framebits, nframes, (hipStream_t)stream);
 }
 
+int vit_decode_varlen_dev_checked(const uint8_t* d_symbols_u8, uint64_t sym_bytes, uint8_t* d_decoded, uint64_t out_bytes,
+                                  const vit_frame_desc* d_desc, int64_t nframes, uint32_t max_framebits, void* stream) {
+    if (hip_device_ready() != VIT_OK) return VIT_ERR_NO_DEVICE;
+    if (!valid_framebits(max_framebits) || nframes < 0 ||
+        (nframes > 0 && (!d_symbols_u8 || !d_decoded || !d_desc))) {
+        set_err("vit_decode_varlen_dev_checked: bad arguments");
+        return VIT_ERR_ARG;
+    }
+    if (nframes == 0 || max_framebits == 0) return VIT_OK;
+    // the checked copy lives in this thread's scratch ON THE CALLER'S CURRENT DEVICE; its reuse across the caller's
+    // streams is ordered by an event, like the u32 path's narrowing buffer
+    int dev = -1;
+    HIPCHK(hipGetDevice(&dev));
+    int rc = ctx_prepare(dev);
+    if (rc != VIT_OK) return rc;
+    const bool fresh = !t_ctx.scratch_ev;
+    if (fresh) HIPCHK(hipEventCreateWithFlags(&t_ctx.scratch_ev, hipEventDisableTiming));
+    if ((rc = grow_dev(&t_ctx.d_desc, &t_ctx.ddesc_cap, (size_t)nframes * sizeof(vit_frame_desc))) != VIT_OK) return rc;
+    if (!fresh) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, t_ctx.scratch_ev, 0));
+    hipError_t e = vit_check_descs_launch(d_desc, (vit_frame_desc*)t_ctx.d_desc, nframes, sym_bytes, out_bytes, (hipStream_t)stream);
+    if (e != hipSuccess) { set_err("descriptor check launch failed: %s", hipGetErrorString(e)); return VIT_ERR_HIP; }
+    rc = launch_decode(decode_mode(), d_symbols_u8, d_decoded, (const vit_frame_desc*)t_ctx.d_desc, 0, max_framebits, nframes,
+                       (hipStream_t)stream);
+    if (rc != VIT_OK) return rc;
+    HIPCHK(hipEventRecord(t_ctx.scratch_ev, (hipStream_t)stream));
+    return VIT_OK;
+}
+
 void vit_sort_descs(vit_frame_desc* h_desc, int64_t nframes) {
     if (!h_desc || nframes <= 1) return;
     std::stable_sort(h_desc, h_desc + nframes,
@@ -595,15 +634,15 @@ static int deconvolve_impl(unsigned int framebits, unsigned int* symbols, unsign
         set_err("deconvolve: bad arguments (framebits=%u)", framebits);
         return 1;
     }
+    if (hip_device_ready() != VIT_OK) return 1;  // before should_batch(): a caller it has counted must reach submit()
     InflightGuard inflight(g_batcher->inflight);
     if (g_batcher->should_batch()) {
-        if (hip_device_ready() != VIT_OK || g_batcher->submit(framebits, symbols, decodedBits) != VIT_OK) {
+        if (g_batcher->submit(framebits, symbols, decodedBits) != VIT_OK) {
             g_fault.store(1);
             return 1;
         }
         return 0;
     }
-    if (hip_device_ready() != VIT_OK) return 1;
     VitDeviceGuard guard(g_device);
     if (ctx_prepare(g_device) != VIT_OK) return 1;
     const size_t nsym = 4u * ((size_t)framebits + VIT_TAIL);

@@ -37,6 +37,10 @@ int64_t vit_lat_capacity(uint32_t max_framebits, int dev);
 // Length-sorted (longest first) copy of a device descriptor table; d_bins = 2*VIT_SORT_BINS words of scratch.
 hipError_t vit_sort_descs_launch(const vit_frame_desc* d_desc, vit_frame_desc* d_sorted, int64_t nframes,
                                  uint32_t max_framebits, unsigned* d_bins, hipStream_t stream);
+// Copy of a device descriptor table in which every descriptor that reaches outside [0, sym_bytes) / [0, out_bytes)
+// has its framebits replaced by 0xFFFFFFFF (skipped by every kernel).
+hipError_t vit_check_descs_launch(const vit_frame_desc* d_desc, vit_frame_desc* d_checked, int64_t nframes,
+                                  uint64_t sym_bytes, uint64_t out_bytes, hipStream_t stream);
 // u32 -> u8 narrowing (low byte), the reference ABI's symbol format to the device format.
 hipError_t vit_launch_pack(const uint32_t* d_sym32, uint8_t* d_sym8, int64_t nsym,
                            hipStream_t stream);

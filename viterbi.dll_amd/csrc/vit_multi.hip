@@ -234,6 +234,14 @@ int run(const uint8_t* d_sym, uint8_t* d_out, uint32_t framebits, int64_t nframe
         }
         if (any) {
             MNCCL(g_rccl.GroupStart());
+            // an error return between GroupStart and GroupEnd must still close the group: RCCL's group depth is
+            // per thread, and the clean-up after a failed call (ncclCommDestroy) runs on this thread
+            struct GroupGuard {
+                bool open = true;
+                ~GroupGuard() {
+                    if (open) (void)g_rccl.GroupEnd();
+                }
+            } group;
             for (int r = 1; r < W; r++) {
                 Rank& k = c.ranks[(size_t)r];
                 int64_t lo, n;
@@ -248,6 +256,7 @@ int run(const uint8_t* d_sym, uint8_t* d_out, uint32_t framebits, int64_t nframe
                     MNCCL(g_rccl.Recv(d_out + (size_t)lo * olen, (size_t)n * olen, ncclUint8, k.comm, c.comms[0], root.s_x));
                 }
             }
+            group.open = false;
             MNCCL(g_rccl.GroupEnd());
         }
         // ---- compute step j ----

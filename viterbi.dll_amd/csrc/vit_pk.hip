@@ -934,7 +934,13 @@ struct ScratchCtx {
         if (ev) (void)hipEventDestroy(ev);
     }
 };
-thread_local ScratchCtx t_scratch;
+// one per (thread, device): vit_decode_stream_multi drives every rank from one host thread, and freeing the other
+// device's scratch at every step (hipFree = device-wide sync) would serialise its double-buffered pipeline
+constexpr int PK_MAX_DEVS = 64;
+struct ScratchCtxs {
+    ScratchCtx by_dev[PK_MAX_DEVS];
+};
+thread_local ScratchCtxs t_scratch;
 constexpr size_t SCRATCH_HDR = 16384;
 constexpr int64_t SORT_MIN_FRAMES = 16;  // below this a table is not worth three extra launches
 
@@ -991,14 +997,14 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
     const u32 spill_blocks = is_long ? nblk - LONG_LDS_BLOCKS : 0u;
     const size_t desc_bytes = sort ? (((size_t)nframes * sizeof(vit_frame_desc) + 255u) & ~(size_t)255u) : 0u;
     const size_t need = SCRATCH_HDR + desc_bytes + (size_t)grid * spill_blocks * DEC_BLOCK;
-    ScratchCtx& sc = t_scratch;
-    if (sc.dev != dev || sc.cap < need) {
+    if (dev < 0 || dev >= PK_MAX_DEVS) return hipErrorInvalidDevice;
+    ScratchCtx& sc = t_scratch.by_dev[dev];
+    if (sc.cap < need) {
         if (sc.buf) (void)hipFree(sc.buf);  // synchronises with the kernels still using it
         sc.buf = nullptr;
         sc.cap = 0;
         if (sc.ev) (void)hipEventDestroy(sc.ev);
         sc.ev = nullptr;
-        if (sc.dev != dev) sc.drop_side();  // streams and events belong to a device
         if ((e = hipMalloc(&sc.buf, need + need / 4)) != hipSuccess) return e;
         sc.cap = need + need / 4;
         sc.dev = dev;

@@ -86,7 +86,33 @@ __global__ __launch_bounds__(TPB) void desc_scatter_kernel(const vit_frame_desc*
     if (i < n) sorted[cnt[key] + rank] = d;
 }
 
+// Bounds check of a descriptor table against the sizes of the caller's two buffers (vit_decode_varlen_dev_checked):
+// the copy keeps every descriptor whose symbols and output bytes lie inside them and gives the others a length no
+// launch is sized for (0xFFFFFFFF), which every decoder kernel skips and the sort puts last.
+__global__ __launch_bounds__(256) void desc_check_kernel(const vit_frame_desc* __restrict__ desc, long long n,
+                                                         unsigned long long sym_bytes, unsigned long long out_bytes,
+                                                         vit_frame_desc* __restrict__ checked) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    vit_frame_desc d = desc[i];
+    if (d.framebits <= VIT_MAX_FRAMEBITS) {
+        const unsigned long long need_in = 4ull * (d.framebits + VIT_TAIL), need_out = (d.framebits + 7u) >> 3;
+        const bool inside = d.sym_offset <= sym_bytes && need_in <= sym_bytes - d.sym_offset &&
+                            d.out_offset <= out_bytes && need_out <= out_bytes - d.out_offset;
+        if (!inside) d.framebits = 0xFFFFFFFFu;
+    }
+    checked[i] = d;
+}
+
 }  // namespace
+
+hipError_t vit_check_descs_launch(const vit_frame_desc* d_desc, vit_frame_desc* d_checked, int64_t nframes,
+                                  uint64_t sym_bytes, uint64_t out_bytes, hipStream_t stream) {
+    if (nframes <= 0) return hipSuccess;
+    hipLaunchKernelGGL(desc_check_kernel, dim3((unsigned)((nframes + 255) / 256)), dim3(256), 0, stream, d_desc,
+                       (long long)nframes, (unsigned long long)sym_bytes, (unsigned long long)out_bytes, d_checked);
+    return hipGetLastError();
+}
 
 hipError_t vit_sort_descs_launch(const vit_frame_desc* d_desc, vit_frame_desc* d_sorted, int64_t nframes,
                                  uint32_t max_framebits, unsigned* d_bins, hipStream_t stream) {

@@ -7,8 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libviterbi.so")
-SOURCES = ["vit_api.hip", "vit_wave.hip", "vit_pk.hip", "vit_sort.hip", "rs_kernels.hip", "vit_multi.hip", "vit_lat.hip"]
-DEPS = SOURCES + ["vit_internal.h", "exports.map"]
+SOURCES = ["vit_api.hip", "vit_wave.hip", "vit_pk.hip", "vit_pk8.hip", "vit_sort.hip", "rs_kernels.hip", "vit_multi.hip", "vit_lat.hip"]
+DEPS = SOURCES + ["vit_internal.h", "vit_pk_dev.h", "exports.map"]
 
 
 def _stale():

@@ -25,6 +25,10 @@ bool vit_pk_supported(uint32_t max_framebits);
 hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, const vit_frame_desc* d_desc,
                          uint32_t framebits, uint32_t max_framebits, int64_t nframes,
                          hipStream_t stream, bool renorm_ge);
+// Packed kernel, 8 frames per wavefront at 2 wavefronts per SIMD (vit_pk8.hip): frames of one segment (framebits <= 778).
+bool vit_pk8_supported(uint32_t max_framebits);
+hipError_t vit_launch_pk8(const void* d_symbols, bool sym32, uint8_t* d_out, const vit_frame_desc* d_desc,
+                          uint32_t framebits, uint32_t max_framebits, int64_t nframes, hipStream_t stream, bool renorm_ge);
 // Latency kernel: one frame per wavefront, one path metric per lane, DPP partner fetches (small launches).
 #define VIT_LAT_MAX_FRAMES 2048  // auto selection: up to two waves per SIMD; beyond that the packed kernel's throughput wins
 // done_flag (optional, nframes == 1 only): a word in host-visible memory that receives done_seq, with system-scope

@@ -51,27 +51,12 @@
 #include <mutex>
 
 #include "vit_internal.h"
+#include "vit_pk_dev.h"
 
 namespace {
 
-typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32;
-
-#define DEV __device__ __forceinline__
-
-DEV us2 U(u32 x) { return __builtin_bit_cast(us2, x); }
-DEV u32 W(us2 x) { return __builtin_bit_cast(u32, x); }
-// v_bfi_b32: (mask & a) | (~mask & b); asm so that hipcc does not split it into and/or chains
-DEV u32 bfi(u32 mask, u32 a, u32 b) {
-    u32 d;
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(mask), "v"(a), "v"(b));
-    return d;
-}
-DEV u32 avg4(u32 a, u32 b) { return __builtin_amdgcn_lerp(a, b, 0x01010101u); }  // pavgb x4
-
 constexpr int TAB_BYTES = 2048;  // 32 steps x 2 pairs x 8 triples x M (4 B); 63-M is one v_sub in the ACS
 constexpr int DEC_BLOCK = 512;   // 16 steps of decisions: 64 lanes x 8 B
-constexpr u32 HI = 0xFF00FF00u;  // +0xFF00 in both halves
 constexpr unsigned PK_SPLIT_DEN = 8;  // a sorted table is split between the kernels when < 1/8 of its frames are long
 
 struct Lanes {
@@ -150,16 +135,6 @@ DEV void exchange(u32& A, u32& B, u32 N0, u32 N1, u32 lane) {
     }
 }
 
-struct Consts {
-    u32 hi;  // 0xFF00FF00 in a VGPR
-    u32 rc;  // renormalisation test constant (wave-uniform, SGPR), see pk_renorm_const()
-};
-// Renormalize256's threshold test as ONE 32-bit add on z = m + 0xFF00 per half: z + c has bit 15 set iff m exceeds the
-// threshold.  The low half always carries out (0xFF00 + 0x80xx >= 2^16), so the high half's constant is one less.
-//   C twins,    deconvolve.cpp:408  `> 150`  (m >= 151): c = 0x8069 -> 0x80688069
-//   MASM twins, decon_avx2.asm:97,114 `cmp sil,150 ; jb` = `>= 150`: c = 0x806A -> 0x8069806A
-__host__ __device__ inline u32 pk_renorm_const(bool ge) { return ge ? 0x8069806Au : 0x80688069u; }
-
 // One trellis step for 4 frames (deconvolve.cpp:352-374 in packed u16 form).
 template <int RHO, int J, bool HIST>
 DEV void acs_step(u32& A, u32& B, u32& acc0, u32& acc1, u32 mt, u32 lane, const Consts& C) {
@@ -195,6 +170,15 @@ DEV void acs_step(u32& A, u32& B, u32& acc0, u32& acc1, u32 mt, u32 lane, const 
         // The subtrahend is per frame, i.e. the same for every lane and both registers of a pair, so it
         // commutes with the lane exchange: the broadcast and the exchange are issued together and
         // the subtraction lands on the exchanged registers (one LDS latency instead of two in a row).
+#if defined(VIT_DIAG_NO_RENORM)
+        exchange<4 - RHO>(A, B, W(n0), W(n1), lane);  // timing-only diagnostic builds: outputs are wrong
+        return;
+#elif defined(VIT_DIAG_NO_K)
+        exchange<4 - RHO>(A, B, W(n0), W(n1), lane);
+        A = W(__builtin_elementwise_sub_sat(U(A), U(C.hi)));
+        B = W(__builtin_elementwise_sub_sat(U(B), U(C.hi)));
+        return;
+#endif
 #if VIT_PAIR_LSB
         const u32 z = (u32)__builtin_amdgcn_ds_bpermute((int)((lane & 1u) << 2), (int)W(n0));  // state 0 of the pair: lane 0 / 1
 #else
@@ -227,6 +211,13 @@ DEV void acs_step(u32& A, u32& B, u32& acc0, u32& acc1, u32 mt, u32 lane, const 
         A = W(__builtin_elementwise_sub_sat(U(A), U(K)));  // -> 0-based representation
         B = W(__builtin_elementwise_sub_sat(U(B), U(K)));
     } else {
+#ifdef VIT_DIAG_SKIP_X
+        if constexpr (RHO == 2) {  // timing-only diagnostic: one exchange in five left out (outputs are wrong)
+            A = W(n0);
+            B = W(n1);
+            return;
+        }
+#endif
         exchange<4 - RHO>(A, B, W(n0), W(n1), lane);
     }
 }
@@ -262,64 +253,6 @@ DEV void steps6(u32 v, u32& A, u32& B, u32& acc0, u32& acc1, const char* th, con
     steps16<true, 6>(v, A, B, acc0, acc1, th, L, lane, C);
     acc0 >>= 7;
     acc1 >>= 7;
-}
-
-// The 8 pavgb-tree metrics of one frame-step: s = its 4 soft symbols (bytes), ns = ~s.
-// metric(c) = avg(avg(s0^B0, s1^B1), avg(s2^B2, s3^B0)) >> 2 for the mask triple
-// c = b0 | b1<<1 | b2<<2 (b3 = b0); bytes of lo = c 0..3, bytes of hi = c 4..7.
-// x ^ 0xFF = ~x, so one v_perm_b32 over {s, ~s} yields the four masked variants of a symbol.
-DEV void met8(u32 s, u32& lo, u32& hi) {
-    const u32 ns = ~s;
-    const u32 r0 = __builtin_amdgcn_perm(ns, s, 0x04000400u);  // s0 ^ B0, byte pos = b0 + 2*b1
-    const u32 r1 = __builtin_amdgcn_perm(ns, s, 0x05050101u);  // s1 ^ B1
-    const u32 r2 = __builtin_amdgcn_perm(ns, s, 0x06060202u);  // s2 ^ B2, byte pos = b0 + 2*b2
-    const u32 r3 = __builtin_amdgcn_perm(ns, s, 0x07030703u);  // s3 ^ B0
-    const u32 P = avg4(r0, r1), Q = avg4(r2, r3);
-    const u32 qlo = __builtin_amdgcn_perm(Q, Q, 0x01000100u);  // Q(b0, b2=0) aligned to P's (b0,b1)
-    const u32 qhi = __builtin_amdgcn_perm(Q, Q, 0x03020302u);  // b2 = 1
-    lo = (avg4(P, qlo) >> 2) & 0x3F3F3F3Fu;
-    hi = (avg4(P, qhi) >> 2) & 0x3F3F3F3Fu;
-}
-
-// Pre-pass for 32 steps: lane = (tau = lane>>1, pair = lane&1) computes the 8 branch metrics of both
-// frames of its pair for step t0+tau and writes its 32 table bytes (M only); no cross-lane traffic.
-DEV void prepass(u32 sa, u32 sb, char* tab, u32 lane, const u32 (&sel)[4]) {
-    u32 alo, ahi, blo, bhi;
-    met8(sa, alo, ahi);  // frame half 0 (low 16 bits of the ACS registers)
-    met8(sb, blo, bhi);  // frame half 1
-    uint4* dst = reinterpret_cast<uint4*>(tab + lane * 32);
-    // sel[k]: byte k of the half-0 word, byte k of the half-1 word, and 0xFF high bytes (+0xFF00) on even steps
-    dst[0] = make_uint4(__builtin_amdgcn_perm(blo, alo, sel[0]), __builtin_amdgcn_perm(blo, alo, sel[1]),
-                        __builtin_amdgcn_perm(blo, alo, sel[2]), __builtin_amdgcn_perm(blo, alo, sel[3]));
-    dst[1] = make_uint4(__builtin_amdgcn_perm(bhi, ahi, sel[0]), __builtin_amdgcn_perm(bhi, ahi, sel[1]),
-                        __builtin_amdgcn_perm(bhi, ahi, sel[2]), __builtin_amdgcn_perm(bhi, ahi, sel[3]));
-}
-
-// The 4 soft symbols of step t of one frame.  SYM32 = the reference ABI's format (one u32 per symbol, low
-// byte used: deconvolve.cpp:158-165) read straight from memory - the ingest narrowing fused into the
-// pre-pass (16 B per step instead of 4, no intermediate u8 buffer).  The load returns the RAW words and the
-// narrowing happens where the symbols are consumed, 32 steps later: packing right after the load would
-// make the wave wait for HBM at every pre-pass.
-template <bool SYM32>
-struct RawStep {
-    typedef u32 type;
-};
-template <>
-struct RawStep<true> {
-    typedef uint4 type;
-};
-template <bool SYM32>
-DEV typename RawStep<SYM32>::type load_step(const uint8_t* frame, u32 t, bool valid) {
-    typedef typename RawStep<SYM32>::type T;
-    if constexpr (!SYM32) {
-        return valid ? reinterpret_cast<const T*>(frame)[t] : 0u;
-    } else {
-        return valid ? reinterpret_cast<const T*>(frame)[t] : make_uint4(0u, 0u, 0u, 0u);
-    }
-}
-DEV u32 pack_step(u32 raw) { return raw; }
-DEV u32 pack_step(const uint4& v) {
-    return __builtin_amdgcn_perm(v.y, v.x, 0x0C0C0400u) | __builtin_amdgcn_perm(v.w, v.z, 0x04000C0Cu);
 }
 
 typedef u32 v32u __attribute__((ext_vector_type(32)));

@@ -172,7 +172,9 @@ int vit_set_batch_min_callers(int min_callers);
 /* Kernel selection (the analogue of the reference's dispatcher, setupdll.cpp:195-270):
  *   0 = auto: launches of up to 2048 frames (they cannot fill the chip) take the latency kernel - one
  *       frame per wavefront, ~20 us per FIC frame -, larger ones the packed throughput kernel;
- *   1 = wave-per-frame cross-check kernel, 2 = packed 4-frames-per-wave kernel, 3 = latency kernel.
+ *   1 = wave-per-frame cross-check kernel, 2 = packed 4-frames-per-wave kernel, 3 = latency kernel,
+ *   4 = packed 8-frames-per-wave kernel (frames <= 778 bits; an experiment kept for comparison: fewer instructions per
+ *       frame, slower - see csrc/vit_pk8.hip).
  * Returns the old value.  Affects later vit_decode_* / deconvolve calls of the whole process. */
 int vit_set_kernel(int which);
 

@@ -214,11 +214,24 @@ bool valid_framebits(uint32_t fb) { return fb <= VIT_MAX_FRAMEBITS && (fb & 1u) 
 // the analogue of setupdll.cpp:195-270's dispatcher: choose the kernel for a batch.  `choice` is the value of
 // vit_set_kernel() READ ONCE by the exported entry point (a concurrent vit_set_kernel must not flip the decision
 // between the check that sizes the scratch buffers and the launch).
-enum { K_AUTO = 0, K_WAVE = 1, K_PACKED = 2, K_LATENCY = 3 };
+enum { K_AUTO = 0, K_WAVE = 1, K_PACKED = 2, K_LATENCY = 3, K_PACKED8 = 4 };
+// Frames of one segment (<= 778 bits) in a uniform-length batch have two packed kernels: 4 frames per wavefront at 4
+// wavefronts per SIMD (vit_pk.hip) and 8 frames per wavefront at 2 per SIMD (vit_pk8.hip).  The second executes 12 % fewer
+// instructions per frame and is 9 % SLOWER on the benchmark batch (two wavefronts cannot hide the LDS round trips of the
+// exchange and of the traceback: profiles/r03_ab_pk8.txt), so it is not the default: VITERBI_AMD_PK8=1 makes K_AUTO /
+// K_PACKED take it, vit_set_kernel(4) forces it (tests, A/B runs).
+bool pk8_default() {
+    static const bool on = [] {
+        const char* e = getenv("VITERBI_AMD_PK8");
+        return e ? atoi(e) != 0 : false;
+    }();
+    return on;
+}
 // which kernel runs a batch: the explicit choice, or for K_AUTO the latency kernel for launches that cannot fill
 // the chip (<= VIT_LAT_MAX_FRAMES wavefronts) and the packed kernel otherwise
 int pick_kernel(int choice, uint32_t max_framebits, int64_t nframes) {
     if (choice == K_WAVE || choice == K_LATENCY) return choice;
+    if (choice == K_PACKED8) return vit_pk8_supported(max_framebits) ? K_PACKED8 : -1;
     if (choice == K_AUTO && nframes <= VIT_LAT_MAX_FRAMES) {  // small launch: does it fit the latency kernel's residency?
         int dev = 0;
         if (hipGetDevice(&dev) == hipSuccess && nframes <= vit_lat_capacity(max_framebits, dev)) return K_LATENCY;
@@ -228,12 +241,14 @@ int pick_kernel(int choice, uint32_t max_framebits, int64_t nframes) {
 int launch_decode(DecodeMode mode, const uint8_t* d_sym, uint8_t* d_out, const vit_frame_desc* d_desc, uint32_t framebits,
                   uint32_t max_framebits, int64_t nframes, hipStream_t s) {
     const int choice = mode.kernel;
-    const int k = pick_kernel(choice, max_framebits, nframes);
+    int k = pick_kernel(choice, max_framebits, nframes);
     if (k < 0) {
         set_err("packed kernel does not support framebits=%u", max_framebits);
         return VIT_ERR_ARG;
     }
-    hipError_t e = k == K_PACKED    ? vit_launch_pk(d_sym, false, d_out, d_desc, framebits, max_framebits, nframes, s, mode.ge)
+    if (k == K_PACKED && !d_desc && pk8_default() && vit_pk8_supported(max_framebits)) k = K_PACKED8;
+    hipError_t e = k == K_PACKED8   ? vit_launch_pk8(d_sym, false, d_out, d_desc, framebits, max_framebits, nframes, s, mode.ge)
+                   : k == K_PACKED  ? vit_launch_pk(d_sym, false, d_out, d_desc, framebits, max_framebits, nframes, s, mode.ge)
                    : k == K_LATENCY ? vit_launch_lat(d_sym, false, d_out, d_desc, framebits, max_framebits, nframes, s, nullptr, 0, mode.ge)
                                     : vit_launch_wave(d_sym, d_out, d_desc, framebits, max_framebits, nframes, s, mode.ge);
     if (e != hipSuccess) {
@@ -246,14 +261,16 @@ int launch_decode(DecodeMode mode, const uint8_t* d_sym, uint8_t* d_out, const v
 // read them directly (narrowing fused into their symbol loads); otherwise they are narrowed into `d_scratch8` first.
 bool u32_in_place(int choice, const void* d_sym32, uint32_t max_framebits, int64_t nframes) {
     const int k = pick_kernel(choice, max_framebits, nframes);
-    return (k == K_PACKED || k == K_LATENCY) && (reinterpret_cast<uintptr_t>(d_sym32) & 15u) == 0;
+    return (k == K_PACKED || k == K_PACKED8 || k == K_LATENCY) && (reinterpret_cast<uintptr_t>(d_sym32) & 15u) == 0;
 }
 int launch_decode_u32(DecodeMode mode, const uint32_t* d_sym32, uint8_t* d_scratch8, uint8_t* d_out, const vit_frame_desc* d_desc,
                       uint32_t framebits, uint32_t max_framebits, int64_t nframes, int64_t nsym, hipStream_t s) {
     const int choice = mode.kernel;
     if (u32_in_place(choice, d_sym32, max_framebits, nframes)) {
-        const int k = pick_kernel(choice, max_framebits, nframes);
-        hipError_t e = k == K_PACKED ? vit_launch_pk(d_sym32, true, d_out, d_desc, framebits, max_framebits, nframes, s, mode.ge)
+        int k = pick_kernel(choice, max_framebits, nframes);
+        if (k == K_PACKED && !d_desc && pk8_default() && vit_pk8_supported(max_framebits)) k = K_PACKED8;
+        hipError_t e = k == K_PACKED8 ? vit_launch_pk8(d_sym32, true, d_out, d_desc, framebits, max_framebits, nframes, s, mode.ge)
+                       : k == K_PACKED ? vit_launch_pk(d_sym32, true, d_out, d_desc, framebits, max_framebits, nframes, s, mode.ge)
                                      : vit_launch_lat(d_sym32, true, d_out, d_desc, framebits, max_framebits, nframes, s, nullptr, 0, mode.ge);
         if (e != hipSuccess) {
             set_err("kernel launch failed: %s", hipGetErrorString(e));
@@ -465,7 +482,7 @@ int vit_set_batch_min_callers(int n) {
 }
 
 int vit_set_kernel(int which) {
-    if (which < K_AUTO || which > K_LATENCY) which = K_AUTO;
+    if (which < K_AUTO || which > K_PACKED8) which = K_AUTO;
     return g_kernel.exchange(which);
 }
 

@@ -318,6 +318,17 @@ constexpr u32 P_ZERO = 252u;
 #define VIT_TB_WARM 30
 #endif
 constexpr u32 TB_WARM = VIT_TB_WARM;  // warm-up steps (multiple of 5) a speculative block starts above its own range
+// Input without signal (uniform random bytes, hard decisions from a dead channel) merges late: after 30 steps back from
+// state 0 half of the blocks are still off the survivor path (3 % at Eb/N0 = 3 dB), after 90 steps 12 %
+// (profiles/r03_merge_depth.txt).  A wave that sees at least TB_HARD_MISSES of its 64 blocks miss in the first pass of its
+// first part traces the remaining parts with the longer warm-up: one long pass instead of a chain of re-trace passes.
+#ifndef VIT_TB_WARM_HARD
+#define VIT_TB_WARM_HARD 90
+#endif
+#ifndef VIT_TB_HARD_MISSES
+#define VIT_TB_HARD_MISSES 8
+#endif
+constexpr u32 TB_WARM_HARD = VIT_TB_WARM_HARD, TB_HARD_MISSES = VIT_TB_HARD_MISSES;
 
 // LDS byte offset, inside a 512-byte decision block, of the (acc1, acc0) pair of ACS lane `lane`:
 // [pair][31 - l][1 - n] - the register with n = 1 first.  Every store of a block uses it.
@@ -390,7 +401,7 @@ DEV
 __device__ __attribute__((noinline))
 #endif
 u32 traceback_part(const char* dec, u32* scratch, u32* img, u32 fstride, u32 lane, u32 ts, u32 te, u32 te_max,
-                       u32 slot0, u32 P_top, u32 dmask = 0xFFFFFFFFu) {
+                       u32 slot0, u32 P_top, u32& warm, u32 dmask = 0xFFFFFFFFu) {
 #ifdef VIT_DIAG_NO_TB
     return P_top;  // timing-only diagnostic build: outputs are wrong
 #endif
@@ -402,7 +413,7 @@ u32 traceback_part(const char* dec, u32* scratch, u32* img, u32 fstride, u32 lan
     const bool has_work = tbase < te;
     const u32 i_last = has_work ? te - 1u - tbase : 0u;  // block-relative index of the frame's last step here
     const u32 q_top = te > ts ? (te - 1u - ts) / BL : 0u;
-    const u32 i_warm = BL - 1u + TB_WARM;
+    const u32 i_warm = BL - 1u + warm;
     const u32 i_start = i_last < i_warm ? i_last : i_warm;
     const bool fixed = has_work && i_last <= i_warm;  // starts from the true position: never re-traced
     // PC = P | C: the lane's constant address bits (pair, half) ride along in the tracked position
@@ -425,7 +436,9 @@ u32 traceback_part(const char* dec, u32* scratch, u32* img, u32 fstride, u32 lan
         const u32 nxt = __shfl_down(P_out, 1);  // the block above belongs to the same frame: same C
         const u32 new_in = (q < q_top) ? nxt : PC_top;
         const bool changed = has_work && !fixed && new_in != P_in;
-        if (!__any(changed)) break;
+        const unsigned long long miss = __ballot(changed);
+        if (miss == 0) break;
+        if (pass == 0 && warm == TB_WARM && (u32)__popcll(miss) >= TB_HARD_MISSES) warm = TB_WARM_HARD;  // for the parts that follow
         if (changed) P_in = new_in;
         P = new_in;
         tb_run<true>(P, scratch, (int)BL - 1, 0, changed, BL - 1u, xbase, j0);
@@ -587,8 +600,9 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
     u32* scratch = reinterpret_cast<u32*>(tab + DEC_BLOCK) + lane * pk_scratch_words(maxfb);  // traceback bit words
     // LDS-resident blocks [R, nb)
     const u32 t_lo = R * 16u;
+    u32 warm = TB_WARM;
     u32 P_part = traceback_part(dec, scratch, img, fstride, lane, t_lo > VIT_TAIL ? t_lo : VIT_TAIL, t_T, T_max, R,
-                                P_ZERO);
+                                P_ZERO, warm);
     // register-resident blocks, 16 at a time from the top
     for (u32 g1 = R; g1 > 0;) {
         const u32 g0 = g1 > DUMP_GROUP ? g1 - DUMP_GROUP : 0u;  // group = blocks [g0, g1)
@@ -602,7 +616,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
         const u32 te = t_T < tend ? t_T : tend, te_max = T_max < tend ? T_max : tend;
         // a frame that reaches beyond this group continues from the position the later part ended in
         const u32 P_top = t_T > tend ? P_part : P_ZERO;
-        P_part = traceback_part(dec, scratch, img, fstride, lane, tsg, te, te_max, g0, P_top);
+        P_part = traceback_part(dec, scratch, img, fstride, lane, tsg, te, te_max, g0, P_top, warm);
         g1 = g0;
     }
     __syncthreads();
@@ -809,7 +823,8 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
                 d[k] = (g0 + k < g1) ? wspill[(size_t)(g0 + k) * 64u] : make_uint2(0u, 0u);
         };
         if (G) fetch(G > DUMP_GROUP ? G - DUMP_GROUP : 0u, G);
-        u32 P_part = traceback_part(dec, scratch, img, IMG_RING, lane, ts_top, t_T, T_max, G, P_ZERO, IMG_RING - 1u);
+        u32 warm = TB_WARM;
+        u32 P_part = traceback_part(dec, scratch, img, IMG_RING, lane, ts_top, t_T, T_max, G, P_ZERO, warm, IMG_RING - 1u);
         flush(ts_top);
         for (u32 g1 = G; g1 > 0;) {
             const u32 g0 = g1 > DUMP_GROUP ? g1 - DUMP_GROUP : 0u;
@@ -822,7 +837,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
             const u32 tsg = g0 ? g0 * 16u : VIT_TAIL, tend = g1 * 16u;
             const u32 te = t_T < tend ? t_T : tend, te_max = T_max < tend ? T_max : tend;
             const u32 P_top = t_T > tend ? P_part : P_ZERO;
-            P_part = traceback_part(dec, scratch, img, IMG_RING, lane, tsg, te, te_max, g0, P_top, IMG_RING - 1u);
+            P_part = traceback_part(dec, scratch, img, IMG_RING, lane, tsg, te, te_max, g0, P_top, warm, IMG_RING - 1u);
             flush(tsg);
             g1 = g0;
         }

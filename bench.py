@@ -207,6 +207,9 @@ def parse_args(argv=None):
     ap.add_argument("--renorm-ge", type=int, default=0,
                     help="1: the MASM decoders' `>= 150` renormalise comparator (vit_set_renorm_ge) instead of the C "
                          "decoders' `> 150`; the parity check then uses the oracle's ge mode (scalar, not the AVX2 port)")
+    ap.add_argument("--input", choices=["noisy", "random"], default="noisy",
+                    help="noisy: reference-style symbols, Eb/N0 = 3 dB (the headline workload); random: uniform random bytes - "
+                         "no signal at all, the traceback's worst case (tests/tools/bench_inputs.py)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-rs", action="store_true", help="skip the second-stage (RScheckSuperframe batch) measurement")
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
@@ -381,6 +384,10 @@ def main(argv=None):
     n = args.frames
     out_len = (FRAMEBITS + 7) // 8
     d_sym = make_frames(n, FRAMEBITS, seed=1234 + rank, device=dev)
+    if args.input == "random":
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234 + rank)
+        d_sym = torch.randint(0, 256, tuple(d_sym.shape), generator=g, dtype=torch.uint8, device=dev)
     d_out = torch.zeros((n, out_len), dtype=torch.uint8, device=dev)
     sync()
 
@@ -481,7 +488,9 @@ def main(argv=None):
             "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": "batch=%d FIC frames (768 bit, 3096 soft symbols u8) per GPU, "
-                                   "resident in HBM; Eb/N0=3 dB reference-style noise" % n,
+                                   "resident in HBM; %s" % (n, "Eb/N0=3 dB reference-style noise" if args.input == "noisy"
+                                                             else "UNIFORM RANDOM BYTES (not the headline workload)"),
+                       "input": args.input,
                        "frames_per_gpu": n, "framebits": FRAMEBITS, "kernel": args.kernel, "renorm_ge": int(bool(args.renorm_ge)),
                        "renorm_comparator": ">= 150 (reference MASM decoders, decon_avx2.asm:97,114)" if args.renorm_ge else
                                             "> 150 (reference C decoders, deconvolve.cpp:408)",
@@ -631,9 +640,9 @@ def _attach_cached_counters(result):
     # the counters belong to ONE configuration (the file records it): attach them only to a run of that configuration
     cfg, mine = pmc.get("config") or {}, result["config"]
     ran = {"frames_per_gpu": mine.get("frames_per_gpu"), "kernel": mine.get("kernel"), "mode": result.get("mode", "shard"),
-           "renorm_ge": mine.get("renorm_ge", 0)}
+           "renorm_ge": mine.get("renorm_ge", 0), "input": mine.get("input", "noisy")}
     want = {"frames_per_gpu": cfg.get("frames_per_gpu", 65536), "kernel": cfg.get("kernel", 0), "mode": cfg.get("mode", "shard"),
-            "renorm_ge": cfg.get("renorm_ge", 0)}
+            "renorm_ge": cfg.get("renorm_ge", 0), "input": cfg.get("input", "noisy")}
     if ran != want:
         r["traffic_source"] = "profiles/pmc_traffic.json was measured for %s, this run is %s: counters not attached" % (want, ran)
         return

@@ -200,7 +200,9 @@ def second_stage(V, dev, nsf=131072, rsdims=24, distinct=256, iters=10):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000,
+                    help="timed steps (default 2000 = 0.9 s of back-to-back launches: long enough for an external GPU-busy "
+                         "sampler to see the timed region; 20 steps measure the same rate within 1 %%, profiles/README.md)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=65536, help="FIC frames per GPU per step")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 wave-per-frame, 2 packed")

@@ -317,6 +317,9 @@ constexpr u32 P_ZERO = 252u;
 #ifndef VIT_TB_WARM
 #define VIT_TB_WARM 30
 #endif
+#ifndef VIT_TB16
+#define VIT_TB16 1  /* the fast traceback form (16-step blocks, straight-line) for waves of four equally long frames */
+#endif
 constexpr u32 TB_WARM = VIT_TB_WARM;  // warm-up steps (multiple of 5) a speculative block starts above its own range
 // Input without signal (uniform random bytes, hard decisions from a dead channel) merges late: after 30 steps back from
 // state 0 half of the blocks are still off the survivor path (3 % at Eb/N0 = 3 dB), after 90 steps 12 %
@@ -465,6 +468,102 @@ u32 traceback_part(const char* dec, u32* scratch, u32* img, u32 fstride, u32 lan
     return __shfl(P_out, (int)(fi * 16u)) & 0xFCu;  // block 0 of the frame ends at step ts; C stripped
 }
 
+// ---- traceback, fast form: blocks of 16 steps, straight-line code (round 3) ---------------------------------------------
+// For a wave whose four frames have the SAME length, a multiple of 16 bits (every DAB size: the FIC's 768, 96*m), the parts
+// are cut top-down, 256 steps each (the lowest one may be shorter, a multiple of 16): part = [lo, lo + 16*nl), lo = 6 mod
+// 16, lane (frame, q) takes the 16 steps from lo + 16q.  Then
+//   * every lane's block-relative index ii has the same bit position (6 + ii) & 15 in its history word and crosses a
+//     16-step history block at the same ii: the bit position is an immediate of v_bfe, the block an immediate offset of
+//     the ds_read, and there is no address arithmetic left but ONE v_or;
+//   * which lanes take part changes at two fixed points only (the two top lanes of a part start late, from the true
+//     position): three straight-line segments under one exec mask each instead of a compare + exec save/restore per step;
+//   * a lane's 16 decoded bits are one halfword of the image: a plain ds_write_b16, no scratch words, no atomics.
+// What is NOT uniform any more is the phase of the lane <-> state map (16 is not a multiple of its period 5): the shift,
+// the bit number and the v_bfi mask of a step come from five per-lane register triples indexed by ii mod 5 (static).
+// A step back is 6 VALU instructions and 21.6 issue cycles (v_or, v_bfe, v_lshrrev, v_and, v_lshl_or, v_bfi) instead of
+// 9 and 37, and a part is 16 + 30 steps instead of 20 + 30.  Same fixed point, same re-trace rule: exactly ChainBack.
+struct Tb16 {
+    u32 sh[5], jj[5], mk[5];  // by ii mod 5: JJ - 2, JJ, (1 << JJ) | 4 with JJ = 7 - ((t - 1) mod 5), t = tbase + ii
+};
+DEV u32 bfi_v(u32 mask, u32 a, u32 b) {
+    u32 d;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(mask), "v"(a), "v"(b));
+    return d;
+}
+template <int II, bool REC>
+DEV void tb16_step(u32& PC, u32& cur, u32 bbq, const Tb16& L) {
+    constexpr int r = II % 5, blk = (6 + II) >> 4, idx = (6 + II) & 15;
+    const u32 w = *reinterpret_cast<const __attribute__((address_space(3))) unsigned short*>((bbq | PC) + (u32)(blk * DEC_BLOCK));
+    const u32 kb = __builtin_amdgcn_ubfe(w, (u32)idx, 1u);
+    const u32 m = (PC >> L.sh[r]) & 4u;
+    const u32 t = (kb << L.jj[r]) | m;
+    PC = bfi_v(L.mk[r], t, PC);
+    if constexpr (REC) cur |= kb << II;
+}
+template <int IFROM, int ITO, bool REC>
+struct Tb16Run {
+    static DEV void run(u32& PC, u32& cur, u32 bbq, const Tb16& L) {
+        tb16_step<IFROM, REC>(PC, cur, bbq, L);
+        if constexpr (IFROM > ITO) Tb16Run<IFROM - 1, ITO, REC>::run(PC, cur, bbq, L);
+    }
+};
+// One part [lo, lo + 16*nl) of four equally long frames; decisions of block b at dec + (b - slot0)*512.  Returns P after step lo.
+DEV u32 traceback_part16(const char* dec, u32* img, u32 fstride, u32 lane, u32 lo, u32 nl, u32 slot0, u32 P_top, u32 dmask) {
+#ifdef VIT_DIAG_NO_TB
+    return P_top;
+#endif
+    constexpr int W = 30;  // warm-up; with 16-step blocks the chain of a speculative lane starts at ii = 45
+    static_assert(TB_WARM == 30, "the straight-line segments below are written for a 30-step warm-up");
+    const u32 fi = lane >> 4, q = lane & 15u;
+    const u32 tbase = lo + q * 16u;
+    const bool has_work = q < nl;
+    const u32 above = nl - q;  // blocks from this one up to the top of the part (has_work: >= 1)
+    const bool fixed = has_work && above <= 2u;  // its warm-up would cross the part's top: it starts there, from the true position
+    const u32 C = (fi >> 1) * 256u + (fi & 1u) * 2u;
+    const u32 dbase = (u32)(uintptr_t)(const __attribute__((address_space(3))) char*)dec;
+    if (dbase & 511u) __builtin_trap();
+    const u32 bbq = dbase + ((lo >> 4) - slot0 + q) * DEC_BLOCK;
+    Tb16 L;
+    {
+        const u32 c = (tbase + 4u) % 5u;  // (tbase - 1) mod 5
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            const u32 e = (c + r) % 5u, JJ = 7u - e;
+            L.sh[r] = JJ - 2u;
+            L.jj[r] = JJ;
+            L.mk[r] = (1u << JJ) | 4u;
+        }
+    }
+    const u32 PC_top = P_top | C;
+    u32 P = fixed ? PC_top : (P_ZERO | C), P_out = PC_top, cur = 0;
+    if (has_work && above >= 3u) Tb16Run<15 + W, 32, false>::run(P, cur, bbq, L);
+    if (has_work && above >= 2u) Tb16Run<31, 16, false>::run(P, cur, bbq, L);
+    u32 P_in = P;
+    if (has_work) {
+        Tb16Run<15, 0, true>::run(P, cur, bbq, L);
+        P_out = P;
+    }
+    for (int pass = 0; pass < 17; pass++) {
+        const u32 nxt = __shfl_down(P_out, 1);
+        const u32 new_in = (q + 1u < nl) ? nxt : PC_top;
+        const bool changed = has_work && !fixed && new_in != P_in;
+        if (!__any(changed)) break;
+        if (changed) {
+            P_in = new_in;
+            P = new_in;
+            cur = 0;
+            Tb16Run<15, 0, true>::run(P, cur, bbq, L);
+            P_out = P;
+        }
+    }
+    // decoded bit index of step t is t - 6 (a multiple of 16 here); decoded bit = NOT stored bit
+    if (has_work) {
+        const u32 h = (tbase - VIT_TAIL) >> 4;  // halfword index in the frame's bit image
+        reinterpret_cast<unsigned short*>(img + fi * fstride)[((h >> 1) & dmask) * 2u + (h & 1u)] = (unsigned short)~cur;
+    }
+    return __shfl(P_out, (int)(fi * 16u)) & 0xFCu;
+}
+
 // Single-segment kernel: every frame of the launch fits 49 blocks (framebits <= 778; the FIC fast path).
 // One workgroup (= one wave) per group of 4 frames, dispatched by the hardware.  A persistent form of this kernel
 // (workgroups looping over groups, static stride or atomic counter, with and without a start-up stagger) was
@@ -599,6 +698,33 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
     const u32 t_fb = fi == 0 ? fbits[0] : fi == 1 ? fbits[1] : fi == 2 ? fbits[2] : fbits[3];
     const u32 t_T = t_fb ? t_fb + VIT_TAIL : 0u;  // steps of this lane's frame
     u32* scratch = reinterpret_cast<u32*>(tab + DEC_BLOCK) + lane * pk_scratch_words(maxfb);  // traceback bit words
+#if VIT_TB16
+    if (fbits[0] == fbits[1] && fbits[1] == fbits[2] && fbits[2] == fbits[3] && (maxfb & 15u) == 0) {
+        // ---- fast form (four equally long frames, a multiple of 16 bits): 256-step parts from the top, a window of 17 blocks ----
+        u32 hi = T_max, slot0 = R, P16 = P_ZERO;
+        for (;;) {
+            const u32 lo = hi > 256u + VIT_TAIL ? hi - 256u : VIT_TAIL;
+            P16 = traceback_part16(dec, img, fstride, lane, lo, (hi - lo) >> 4, slot0, P16, 0xFFFFFFFFu);
+            if (lo == VIT_TAIL) break;
+            // the window moves down by d blocks: what stays goes d slots up (every lane moves its own 8 bytes of a block), the
+            // d register blocks below come in
+            const u32 d = slot0 < DUMP_GROUP ? slot0 : DUMP_GROUP;
+            __syncthreads();
+            for (u32 sl = DUMP_GROUP; sl + 1u > d; sl--) {  // sl = 16 .. d
+                *reinterpret_cast<uint2*>(dec + sl * DEC_BLOCK + dslot) = *reinterpret_cast<const uint2*>(dec + (sl - d) * DEC_BLOCK + dslot);
+                if (sl == 0) break;
+            }
+            const u32 g0 = slot0 - d;
+#pragma unroll
+            for (u32 b = 0; b < VREG_BLOCKS; b++)
+                if (b >= g0 && b < slot0)
+                    *reinterpret_cast<uint2*>(dec + (b - g0) * DEC_BLOCK + dslot) = make_uint2(r1[b], r0[b]);
+            __syncthreads();
+            slot0 = g0;
+            hi = lo;
+        }
+    } else {
+#endif
     // LDS-resident blocks [R, nb)
     const u32 t_lo = R * 16u;
     u32 warm = TB_WARM;
@@ -620,6 +746,9 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
         P_part = traceback_part(dec, scratch, img, fstride, lane, tsg, te, te_max, g0, P_top, warm);
         g1 = g0;
     }
+#if VIT_TB16
+    }
+#endif
     __syncthreads();
 
     // bit b of the image is decoded bit b; output bytes are MSB-first (deconvolve.cpp:432-433)

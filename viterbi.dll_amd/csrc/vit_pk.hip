@@ -710,10 +710,8 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
             // d register blocks below come in
             const u32 d = slot0 < DUMP_GROUP ? slot0 : DUMP_GROUP;
             __syncthreads();
-            for (u32 sl = DUMP_GROUP; sl + 1u > d; sl--) {  // sl = 16 .. d
+            for (u32 sl = DUMP_GROUP; sl >= d; sl--)  // sl = 16 .. d (d >= 1: there are blocks below this part)
                 *reinterpret_cast<uint2*>(dec + sl * DEC_BLOCK + dslot) = *reinterpret_cast<const uint2*>(dec + (sl - d) * DEC_BLOCK + dslot);
-                if (sl == 0) break;
-            }
             const u32 g0 = slot0 - d;
 #pragma unroll
             for (u32 b = 0; b < VREG_BLOCKS; b++)
@@ -900,7 +898,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
                 else
                     steps16<true>(v, A, B, acc0, acc1, tab + (rb & 1u) * 1024u, L, lane, C);
                 if (rb < G) {
-                    wspill[(size_t)rb * 64u] = make_uint2(acc0, acc1);
+                    wspill[(size_t)rb * 64u] = make_uint2(acc1, acc0);  // the order of the LDS blocks: a reload is a plain copy
                 } else {
                     if (rb + 1u == nblk) __syncthreads();  // the last block lands on the table: all reads done first
                     *reinterpret_cast<uint2*>(dec + (rb - G) * DEC_BLOCK + dslot) = make_uint2(acc1, acc0);
@@ -953,6 +951,33 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
                 d[k] = (g0 + k < g1) ? wspill[(size_t)(g0 + k) * 64u] : make_uint2(0u, 0u);
         };
         if (G) fetch(G > DUMP_GROUP ? G - DUMP_GROUP : 0u, G);
+#if VIT_TB16
+        if (fbits[0] == fbits[1] && fbits[1] == fbits[2] && fbits[2] == fbits[3] && (maxfb & 15u) == 0) {
+            // ---- fast form (see traceback_part16): 256-step parts from the top; the 17-block window moves down through the
+            // spilled blocks, the next group is in flight (in registers) while a part is traced back ----
+            u32 hi = T_max, slot0 = G, P16 = P_ZERO;
+            for (;;) {
+                const u32 lo = hi > 256u + VIT_TAIL ? hi - 256u : VIT_TAIL;
+                P16 = traceback_part16(dec, img, IMG_RING, lane, lo, (hi - lo) >> 4, slot0, P16, IMG_RING - 1u);
+                flush(lo);
+                if (lo == VIT_TAIL) break;
+                const u32 dn = slot0 < DUMP_GROUP ? slot0 : DUMP_GROUP;  // the fetched group is blocks [slot0 - dn, slot0)
+                __syncthreads();
+                for (u32 sl = DUMP_GROUP; sl >= dn; sl--) {  // what stays moves dn slots up (dn >= 1 here)
+                    *reinterpret_cast<uint2*>(dec + sl * DEC_BLOCK + dslot) = *reinterpret_cast<const uint2*>(dec + (sl - dn) * DEC_BLOCK + dslot);
+                }
+#pragma unroll
+                for (u32 k = 0; k < DUMP_GROUP; k++)
+                    if (k < dn) *reinterpret_cast<uint2*>(dec + k * DEC_BLOCK + dslot) = d[k];
+                __syncthreads();
+                slot0 -= dn;
+                if (slot0) fetch(slot0 > DUMP_GROUP ? slot0 - DUMP_GROUP : 0u, slot0);
+                hi = lo;
+            }
+            __syncthreads();
+            continue;
+        }
+#endif
         u32 warm = TB_WARM;
         u32 P_part = traceback_part(dec, scratch, img, IMG_RING, lane, ts_top, t_T, T_max, G, P_ZERO, warm, IMG_RING - 1u);
         flush(ts_top);
@@ -961,7 +986,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
             __syncthreads();
 #pragma unroll
             for (u32 k = 0; k < DUMP_GROUP; k++)
-                *reinterpret_cast<uint2*>(dec + k * DEC_BLOCK + dslot) = make_uint2(d[k].y, d[k].x);
+                *reinterpret_cast<uint2*>(dec + k * DEC_BLOCK + dslot) = d[k];
             __syncthreads();
             if (g0) fetch(g0 > DUMP_GROUP ? g0 - DUMP_GROUP : 0u, g0);  // next group down, in flight during this part
             const u32 tsg = g0 ? g0 * 16u : VIT_TAIL, tend = g1 * 16u;

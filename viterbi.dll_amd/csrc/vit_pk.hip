@@ -480,8 +480,8 @@ u32 traceback_part(const char* dec, u32* scratch, u32* img, u32 fstride, u32 lan
 //   * a lane's 16 decoded bits are one halfword of the image: a plain ds_write_b16, no scratch words, no atomics.
 // What is NOT uniform any more is the phase of the lane <-> state map (16 is not a multiple of its period 5): the shift,
 // the bit number and the v_bfi mask of a step come from five per-lane register triples indexed by ii mod 5 (static).
-// A step back is 6 VALU instructions and 21.6 issue cycles (v_or, v_bfe, v_lshrrev, v_and, v_lshl_or, v_bfi) instead of
-// 9 and 37, and a part is 16 + 30 steps instead of 20 + 30.  Same fixed point, same re-trace rule: exactly ChainBack.
+// A step back is 5 VALU instructions and 18.9 issue cycles (v_bfe, v_lshrrev, v_and, v_lshl_or, v_bfi; the tracked value is
+// the LDS address itself) instead of 9 and 37, and a part is 16 + 30 steps instead of 20 + 30.  Same fixed point, same re-trace rule: exactly ChainBack.
 struct Tb16 {
     u32 sh[5], jj[5], mk[5];  // by ii mod 5: JJ - 2, JJ, (1 << JJ) | 4 with JJ = 7 - ((t - 1) mod 5), t = tbase + ii
 };
@@ -490,10 +490,11 @@ DEV u32 bfi_v(u32 mask, u32 a, u32 b) {
     asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(mask), "v"(a), "v"(b));
     return d;
 }
+// PC carries the lane's block base (a multiple of 512, bits 9 and up, which the v_bfi never touches): it IS the LDS address.
 template <int II, bool REC>
-DEV void tb16_step(u32& PC, u32& cur, u32 bbq, const Tb16& L) {
+DEV void tb16_step(u32& PC, u32& cur, const Tb16& L) {
     constexpr int r = II % 5, blk = (6 + II) >> 4, idx = (6 + II) & 15;
-    const u32 w = *reinterpret_cast<const __attribute__((address_space(3))) unsigned short*>((bbq | PC) + (u32)(blk * DEC_BLOCK));
+    const u32 w = *reinterpret_cast<const __attribute__((address_space(3))) unsigned short*>(PC + (u32)(blk * DEC_BLOCK));
     const u32 kb = __builtin_amdgcn_ubfe(w, (u32)idx, 1u);
     const u32 m = (PC >> L.sh[r]) & 4u;
     const u32 t = (kb << L.jj[r]) | m;
@@ -502,9 +503,9 @@ DEV void tb16_step(u32& PC, u32& cur, u32 bbq, const Tb16& L) {
 }
 template <int IFROM, int ITO, bool REC>
 struct Tb16Run {
-    static DEV void run(u32& PC, u32& cur, u32 bbq, const Tb16& L) {
-        tb16_step<IFROM, REC>(PC, cur, bbq, L);
-        if constexpr (IFROM > ITO) Tb16Run<IFROM - 1, ITO, REC>::run(PC, cur, bbq, L);
+    static DEV void run(u32& PC, u32& cur, const Tb16& L) {
+        tb16_step<IFROM, REC>(PC, cur, L);
+        if constexpr (IFROM > ITO) Tb16Run<IFROM - 1, ITO, REC>::run(PC, cur, L);
     }
 };
 // One part [lo, lo + 16*nl) of four equally long frames; decisions of block b at dec + (b - slot0)*512.  Returns P after step lo.
@@ -534,14 +535,15 @@ DEV u32 traceback_part16(const char* dec, u32* img, u32 fstride, u32 lane, u32 l
             L.mk[r] = (1u << JJ) | 4u;
         }
     }
+    // positions travel between lanes without the block base (P & 0x1FF); a lane adds its own
     const u32 PC_top = P_top | C;
-    u32 P = fixed ? PC_top : (P_ZERO | C), P_out = PC_top, cur = 0;
-    if (has_work && above >= 3u) Tb16Run<15 + W, 32, false>::run(P, cur, bbq, L);
-    if (has_work && above >= 2u) Tb16Run<31, 16, false>::run(P, cur, bbq, L);
-    u32 P_in = P;
+    u32 P = (fixed ? PC_top : (P_ZERO | C)) | bbq, P_out = PC_top, cur = 0;
+    if (has_work && above >= 3u) Tb16Run<15 + W, 32, false>::run(P, cur, L);
+    if (has_work && above >= 2u) Tb16Run<31, 16, false>::run(P, cur, L);
+    u32 P_in = P & 0x1FFu;
     if (has_work) {
-        Tb16Run<15, 0, true>::run(P, cur, bbq, L);
-        P_out = P;
+        Tb16Run<15, 0, true>::run(P, cur, L);
+        P_out = P & 0x1FFu;
     }
     for (int pass = 0; pass < 17; pass++) {
         const u32 nxt = __shfl_down(P_out, 1);
@@ -550,10 +552,10 @@ DEV u32 traceback_part16(const char* dec, u32* img, u32 fstride, u32 lane, u32 l
         if (!__any(changed)) break;
         if (changed) {
             P_in = new_in;
-            P = new_in;
+            P = new_in | bbq;
             cur = 0;
-            Tb16Run<15, 0, true>::run(P, cur, bbq, L);
-            P_out = P;
+            Tb16Run<15, 0, true>::run(P, cur, L);
+            P_out = P & 0x1FFu;
         }
     }
     // decoded bit index of step t is t - 6 (a multiple of 16 here); decoded bit = NOT stored bit

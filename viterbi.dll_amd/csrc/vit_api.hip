@@ -217,7 +217,7 @@ bool valid_framebits(uint32_t fb) { return fb <= VIT_MAX_FRAMEBITS && (fb & 1u) 
 enum { K_AUTO = 0, K_WAVE = 1, K_PACKED = 2, K_LATENCY = 3, K_PACKED8 = 4 };
 // Frames of one segment (<= 778 bits) in a uniform-length batch have two packed kernels: 4 frames per wavefront at 4
 // wavefronts per SIMD (vit_pk.hip) and 8 frames per wavefront at 2 per SIMD (vit_pk8.hip).  The second executes 12 % fewer
-// instructions per frame and is 9 % SLOWER on the benchmark batch (two wavefronts cannot hide the LDS round trips of the
+// instructions per frame (8 % fewer than the shipped kernel since its fast traceback form) and is 14 % SLOWER on the benchmark batch (two wavefronts cannot hide the LDS round trips of the
 // exchange and of the traceback: profiles/r03_ab_pk8.txt), so it is not the default: VITERBI_AMD_PK8=1 makes K_AUTO /
 // K_PACKED take it, vit_set_kernel(4) forces it (tests, A/B runs).
 bool pk8_default() {

@@ -39,6 +39,10 @@
 // from the true position when that reaches the frame end), checked against the
 // block above and re-traced until nothing changes.  The last block really starts
 // in state 0 (tail-terminated), so the fixed point is exactly the serial chainback.
+// Two forms: the general one (any mix of lengths in a wave, 20-step blocks, a loop
+// with a predicate per step) and, since round 3, a fast one for waves of four equally
+// long frames of a multiple of 16 bits - every DAB size -: 16-step blocks in
+// straight-line code, 5 instead of 9 instructions per step back (traceback_part16).
 //
 // Instruction costs that shaped this (profiles/r01_valu_issue_rates_ubench.txt): v_pk_*,
 // VOP3 three-operand, DPP, SDWA, v_cmp = 4 cycles per wave; plain VOP2 = 2;

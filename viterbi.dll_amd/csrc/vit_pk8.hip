@@ -5,8 +5,9 @@
 // is bound by VALU issue, and part of its instructions does not scale with the frames in a wave (profiles/r03_ab_diag.txt:
 // renormalisation constant 7 %, traceback - mostly its speculative warm-up - 11 %, per-workgroup set-up 3 %).  This kernel
 // carries eight frames for the same per-wave work of that kind and moves no data in one trellis step of five:
-// 3671 VALU instructions per frame instead of 4162 (-11.8 %, PMC).  Measured on the 65536-frame FIC batch it is 9 %
-// SLOWER (0.505 vs 0.461 ms, profiles/r03_ab_pk8.txt): 18.3 KB of LDS and ~210 VGPRs per wave allow two waves per SIMD,
+// 3671 VALU instructions per frame instead of 4162 (-11.8 %, PMC; the shipped kernel has since come down to 3975 with its
+// fast traceback form).  Measured on the 65536-frame FIC batch it is 9 % SLOWER than the shipped kernel was at the time
+// (0.505 vs 0.461 ms, profiles/r03_ab_pk8.txt; 0.442 ms at the end of round 3): 18.3 KB of LDS and ~210 VGPRs per wave allow two waves per SIMD,
 // and two instruction streams do not hide the LDS round trips of the exchange (ACS phase: 94 % VALU busy after the
 // two-stage software pipeline below, 0.420 vs 0.409 ms without traceback) nor, above all, the dependent LDS reads of the
 // traceback (one chain per wave: 0.085 ms against 0.052 ms for twice the waves in vit_pk.hip).

@@ -602,6 +602,13 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
             case 2: __builtin_amdgcn_s_setprio(2); break;
             default: __builtin_amdgcn_s_setprio(3); break;
         }
+#ifdef VIT_STAGGER
+        // experiment: a start-up offset per wave slot (and SIMD) in units of 64 cycles
+        {
+            const u32 k = (hwid & 3u) * 4u + ((hwid >> 4) & 3u);
+            for (u32 i = 0; i < k; i++) __builtin_amdgcn_s_sleep(VIT_STAGGER);
+        }
+#endif
     }
 #endif
 

@@ -596,6 +596,9 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
     {
         u32 hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+#ifdef VIT_PRIO_FIRST
+        if (blockIdx.x < VIT_PRIO_FIRST)  // experiment: priorities only for the waves of the first round
+#endif
         switch (hwid & 3u) {  // wave slot within the SIMD
             case 0: __builtin_amdgcn_s_setprio(0); break;
             case 1: __builtin_amdgcn_s_setprio(1); break;

@@ -64,6 +64,19 @@ def test_decode_parity_long_frames(V, O, torch_cuda, framebits, kernel):
     assert np.array_equal(got, want)
 
 
+def test_fast_traceback_form_every_multiple_of_16(V, O, torch_cuda):
+    """the straight-line traceback form (csrc/vit_pk.hip traceback_part16: waves of four equally long frames, a multiple
+    of 16 bits) over EVERY such length up to 1600 bits - all register/LDS window shapes of the single-segment kernel
+    (R = 0..32, partial last window shift) and the first spilled groups of the long-frame kernel - plus long ones; 12
+    frames = three uniform waves; reference-style noise, uniform bytes and hard decisions (re-trace passes)"""
+    lengths = list(range(16, 1601, 16)) + [2048, 3056, 4096, 4112, 5008, 6912, 9200, 9216]
+    for fb in lengths:
+        sym = np.concatenate([_mixed_input(O, 8, fb, seed=fb), O.hard_random_symbols(4, fb, seed=fb + 5)])
+        want = O.decode_batch(fb, sym, nthreads=8)
+        got = _gpu_decode(V, torch_cuda, sym, fb, 2)
+        assert np.array_equal(got, want), "framebits=%d" % fb
+
+
 def test_auto_kernel_handles_max_length(V, O, torch_cuda):
     framebits, n = 9216, 5
     sym = _mixed_input(O, n, framebits, seed=5)

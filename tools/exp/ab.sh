@@ -4,6 +4,6 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 for i in 1 2 3; do
   for v in base "$@"; do
     if [ "$v" = base ]; then unset VITERBI_AMD_LIB; else export VITERBI_AMD_LIB=$R/tools/exp/libviterbi_$v.so; fi
-    python3 $R/bench.py --no-cpu --steps 30 --warmup 3 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['roofline']['kernel_ms'], d['value'])"
+    python3 $R/bench.py --no-cpu --no-pipelined --steps 30 --warmup 3 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['roofline']['kernel_ms'], d['value'])"
   done
 done

@@ -24,7 +24,7 @@ lines.append("# %s — bench.py (default flags) on MI355X\n" % tag)
 lines.append("value %.1f %s, ms_per_step %.4f, roofline %s\n" % (bench["value"], bench["unit"], bench["ms_per_step"], json.dumps(bench["roofline"])))
 lines.append("cpu_baseline %s\nparity %s\n" % (json.dumps(bench.get("cpu_baseline")), json.dumps(bench.get("parity"))))
 
-lines.append("\n# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu   (kernel_stats.csv, top rows)\n")
+lines.append("\n# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu --no-pipelined   (kernel_stats.csv, top rows; the bench line's `pipelined` leg is left out: its overlapping launches are not what roofline.kernel_ms prices)\n")
 with open(os.path.join(src, "kernel_stats.csv")) as f:
     rows = list(csv.DictReader(f))
 avg_ns = None

@@ -98,6 +98,10 @@ def test_bench_through_its_spawn_path(torch_cuda):
     # the second stage of the path (RScheckSuperframe in batch) rides along at N = 1, checked against its construction
     ss = r["second_stage"]
     assert ss["outputs_and_return_values_as_constructed"] is True and ss["roofline"]["achieved"] > 100, ss
+    # a plain N = 1 run also carries the two-stream leg next to `value`, with both of its output buffers equal
+    r1 = _bench(["--frames", "8192", "--no-rs"])
+    assert r1["pipelined"]["streams"] == 2 and r1["pipelined"]["both_output_buffers_equal"] is True and r1["pipelined"]["value"] > 1000
+    assert "pipelined" not in _bench(["--frames", "8192", "--no-rs", "--no-pipelined"])
     r = _bench(["--gpus", "1", "--spawn", "--frames", "8192", "--mode", "scatter", "--chunk-frames", "1024"])
     assert r["n_gpus"] == 1 and r["value"] > 1000
     r = _bench(["--gpus", "1", "--frames", "8192", "--mode", "multi", "--chunk-frames", "1024", "--loopback"])

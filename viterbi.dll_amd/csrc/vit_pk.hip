@@ -322,7 +322,8 @@ constexpr u32 P_ZERO = 252u;
 #define VIT_TB_WARM 30
 #endif
 #ifndef VIT_TB16
-#define VIT_TB16 1  /* the fast traceback form (16-step blocks, straight-line) for waves of four equally long frames */
+#define VIT_TB16 (VIT_TB_WARM == 30)  /* the fast traceback form (16-step blocks, straight-line code written for a 30-step
+                                         warm-up) for waves of four equally long frames */
 #endif
 constexpr u32 TB_WARM = VIT_TB_WARM;  // warm-up steps (multiple of 5) a speculative block starts above its own range
 // Input without signal (uniform random bytes, hard decisions from a dead channel) merges late: after 30 steps back from
@@ -518,7 +519,6 @@ DEV u32 traceback_part16(const char* dec, u32* img, u32 fstride, u32 lane, u32 l
     return P_top;
 #endif
     constexpr int W = 30;  // warm-up; with 16-step blocks the chain of a speculative lane starts at ii = 45
-    static_assert(TB_WARM == 30, "the straight-line segments below are written for a 30-step warm-up");
     const u32 fi = lane >> 4, q = lane & 15u;
     const u32 tbase = lo + q * 16u;
     const bool has_work = q < nl;

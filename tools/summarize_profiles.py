@@ -123,8 +123,8 @@ vc = int(meta.get("VGPR_Count", 0) or 0)
 lines.append("\n# note on the dispatch columns of rocprofv3's counter CSV: VGPR_Count %d = (granulated_workitem_vgpr_count + 1) * 4,\n"
              "# i.e. the kernel descriptor's %d granules priced at the pre-gfx90a granule of 4; gfx950 allocates in granules of 8, so\n"
              "# the wave holds %d * 8 = %d registers (the code object's .vgpr_count rounded up: 114 in rounds 1-2, 128 since the fast\n"
-             "# traceback form; 512 / %d -> %d waves per SIMD).\n" % (vc, vc // 4, vc // 4, vc * 2, vc * 2, 512 // max(vc * 2, 1))
-             "# LDS_Block_Size 0 is the STATIC group segment (.group_segment_fixed_size 0); the 10240 B per workgroup are DYNAMIC LDS\n"
+             "# traceback form; 512 / %d -> %d waves per SIMD).\n" % (vc, vc // 4, vc // 4, vc * 2, vc * 2, 512 // max(vc * 2, 1)))
+lines.append("# LDS_Block_Size 0 is the STATIC group segment (.group_segment_fixed_size 0); the 10240 B per workgroup are DYNAMIC LDS\n"
              "# passed at launch (hipLaunchKernelGGL's sharedMemBytes), and they are what limits residency to 16 waves per CU.\n")
 open(os.path.join(dst, "%s_rocprof_summary.txt" % tag), "w").writelines(lines)
 print("".join(lines))

@@ -81,8 +81,13 @@ constexpr QuadTable make_quad_table() {
 // different nibbles different banks.  One 256-row table needs one lookup per step instead of two, but 64 random rows
 // cost it ~3x the conflict-free cycles: 0.27 ms per 131072 superframes against 0.18 ms with conflict-free rows
 // (measured with a fake index, profiles/r02_ab_rs_chien.txt), and that loop is LDS-bound.
+#ifndef RS_LFSR2
+#define RS_LFSR2 1  /* two data bytes per LFSR step: four independent lookups, half the dependent chain, 9 instead of 11
+                       instructions per byte (0.195 against 0.201 ms per 131072 clean superframes, profiles/r03_ab_rs_lfsr2.txt) */
+#endif
+constexpr int NIB_TABLES = RS_LFSR2 ? 4 : 2;
 struct NibTable {
-    uint32_t w[2 * 16 * 4];  // LO rows, then HI rows
+    uint32_t w[NIB_TABLES * 16 * 4];  // LO rows, then HI rows (RS_LFSR2: then the LO and HI rows of the two-step table)
 };
 constexpr NibTable make_nib_table() {
     const GfTables t = make_tables();
@@ -107,6 +112,20 @@ constexpr NibTable make_nib_table() {
                 G.w[(half * 16 + n) * 4 + (j < 8 ? j / 4 : 3)] |= prod << (8 * (j % 4));  // g_8, g_9 in dword 3
             }
         }
+#if RS_LFSR2
+    // Two steps at once: r'' = shift2(r; d1, d2) + Row(r_8) + Row2(r_9) with Row2(a)_j = a * (g_(j-1) + g_9 * g_j), g_(-1) = 0
+    // (the second step's feedback byte is r_8 + r_9 * g_9, and Row is linear)
+    for (int half = 0; half < 2; half++)
+        for (int n = 1; n < 16; n++) {
+            const int x = half ? n << 4 : n;
+            for (int j = 0; j < NROOTS; j++) {
+                uint8_t c = j ? g[j - 1] : 0;
+                if (g[9] && g[j]) c ^= t.ato[t.iof[g[9]] + t.iof[g[j]]];
+                const uint32_t prod = c ? t.ato[t.iof[x] + t.iof[c]] : 0u;
+                G.w[((2 + half) * 16 + n) * 4 + (j < 8 ? j / 4 : 3)] |= prod << (8 * (j % 4));
+            }
+        }
+#endif
     return G;
 }
 __constant__ NibTable g_nib = make_nib_table();
@@ -488,7 +507,8 @@ __device__ int decode_rs(bool active, uint32_t sfid, uint8_t* cw, uint32_t tid, 
 
 // Natural-layout front end (codeword byte k at cwbase[coloff + k * stride]): remainder modulo g(x) by LFSR,
 // r <- r*x + d_k - r_9*(x^10 + g(x)): two conflict-free 16-byte lookups (low and high nibble of the feedback byte,
-// see NibTable) per data byte.  Called by all lanes; the ones without a column (active == false) walk a valid one
+// see NibTable) per data byte; two bytes per trip (RS_LFSR2: the second feedback byte is linear in r_8 and r_9, so its
+// row is folded into a second pair of tables and all four lookups of a trip start from the same register).  Called by all lanes; the ones without a column (active == false) walk a valid one
 // and drop the result.
 __device__ int decode_rs_lfsr(bool active, uint32_t sfid, uint8_t* cwbase, uint32_t coloff, uint32_t stride,
                               const uint8_t* __restrict__ ato, const uint8_t* __restrict__ iof,
@@ -497,10 +517,34 @@ __device__ int decode_rs_lfsr(bool active, uint32_t sfid, uint8_t* cwbase, uint3
     uint32_t r0 = 0, r1 = 0, r2 = 0;  // coefficient r_j = byte j of the 80-bit register (r2 above bit 15: junk)
     const uint8_t* q = cwbase + coloff;
     const uint32_t nibbase = (uint32_t)(uintptr_t)(const LDS uint32_t*)gnib;  // LDS byte address
+#if RS_LFSR2
+    static_assert(NCW % 2 == 0, "two data bytes per step");
+#pragma unroll 4
+    for (int k = 0; k < NCW; k += 2, q += 2 * stride) {
+        const uint32_t d1 = q[0], d2 = q[stride];
+        const uint32_t a4 = r2 >> 4;  // bits 4..11 = r_9; r_8 = bits 0..7 of r2
+        const u32x4 lo2 = *reinterpret_cast<const LDS u32x4*>(nibbase + 512u + (a4 & 0xF0u));
+        const u32x4 hi2 = *reinterpret_cast<const LDS u32x4*>(nibbase + 768u + ((a4 >> 4) & 0xF0u));
+        const u32x4 lo1 = *reinterpret_cast<const LDS u32x4*>(nibbase + ((r2 << 4) & 0xF0u));
+        const u32x4 hi1 = *reinterpret_cast<const LDS u32x4*>(nibbase + 256u + (r2 & 0xF0u));
+        r2 = xor3(xor3(__builtin_amdgcn_alignbit(r2, r1, 16), lo1.w, hi1.w), lo2.w, hi2.w);
+        r1 = xor3(xor3(__builtin_amdgcn_alignbit(r1, r0, 16), lo1.y, hi1.y), lo2.y, hi2.y);
+        r0 = xor3(xor3((((r0 << 16) | d2) | (d1 << 8)), lo1.x, hi1.x), lo2.x, hi2.x);
+        asm volatile("" ::"v"(lo1.z), "v"(hi1.z), "v"(lo2.z), "v"(hi2.z));
+    }
+#else
 #pragma unroll 8
     for (int k = 0; k < NCW; k++, q += stride) {
+#ifdef RS_DIAG_NO_DATA
+        const uint32_t d = (uint32_t)k;  // timing-only diagnostic: no data byte read (outputs wrong)
+#else
         const uint32_t d = *q;
+#endif
+#ifdef RS_DIAG_FAKE_IDX
+        const uint32_t f4 = (uint32_t)k << 4;  // timing-only diagnostic: every lane reads the same rows (outputs wrong)
+#else
         const uint32_t f4 = r2 >> 4;  // bits 4..11 = r_9
+#endif
         // g_8, g_9 sit in the LAST dword of a row (the third is empty) so that the access stays ONE ds_read_b128
         // (4 LDS cycles per wave): with the payload in the first 12 bytes the compiler narrows it to ds_read_b96,
         // which takes 8 (measured: 0.36 ms against 0.20 per 131072 superframes of RSDims 24)
@@ -513,6 +557,7 @@ __device__ int decode_rs_lfsr(bool active, uint32_t sfid, uint8_t* cwbase, uint3
         // would put a wait for the lookup in front of its computation
         asm volatile("" ::"v"(lo.z), "v"(hi.z));
     }
+#endif
     r2 &= 0xFFFFu;
     const bool err = active && (r0 | r1 | r2) != 0;
     if (!__any(err)) return 0;
@@ -642,14 +687,14 @@ __device__ __forceinline__ void copy_out(uint8_t* dst0, const uint8_t* cw, const
 }
 
 // rsdims <= 256: spb = 256/rsdims superframes per pass, natural layout in LDS (see the header comment).
-// LDS: 30720 (codewords) + 5120 (Chien steps) + 512 (LFSR nibble rows) + 768 + 256 + 256 + 2048 = 39680 B: four workgroups
+// LDS: 30720 (codewords) + 5120 (Chien steps) + 1024 (LFSR nibble rows) + 768 + 256 + 256 + 2048 = 40192 B: four workgroups
 // share a CU (second launch bound: 4 waves per SIMD); a three-workgroup build was 6 % slower on clean data
 // (profiles/r02_ab_rs_chien.txt).
 __global__ __launch_bounds__(RS_THREADS, 4) void rs_kernel(const uint8_t* __restrict__ p, uint8_t* __restrict__ out,
                                                         int32_t* __restrict__ ret, uint32_t rsdims,
                                                         long long nsf, int host_polls_ret) {
     __shared__ __attribute__((aligned(16))) uint8_t cw[NCW * RS_THREADS];  // [superframe][row][column]
-    __shared__ __attribute__((aligned(256))) uint32_t gnib[2 * 16 * 4];
+    __shared__ __attribute__((aligned(256))) uint32_t gnib[NIB_TABLES * 16 * 4];
     __shared__ uint32_t step[STEP_TERMS * 256];
     __shared__ uint8_t ato[ATO_SIZE];
     __shared__ uint8_t iof[256];
@@ -660,7 +705,7 @@ __global__ __launch_bounds__(RS_THREADS, 4) void rs_kernel(const uint8_t* __rest
     for (uint32_t i = tid; i < ATO_SIZE; i += RS_THREADS) ato[i] = g_gf.ato[i];
     iof[tid] = g_gf.iof[tid];
     qsol[tid] = g_quad.q[tid];
-    if (tid < 2u * 16u * 4u) gnib[tid] = g_nib.w[tid];
+    if (tid < (uint32_t)NIB_TABLES * 16u * 4u) gnib[tid] = g_nib.w[tid];
     for (uint32_t i = tid; i < STEP_TERMS * 256u; i += RS_THREADS) step[i] = g_step.w[i];
     __syncthreads();
 

@@ -63,6 +63,10 @@ constexpr int TAB_BYTES = 2048;  // 32 steps x 2 pairs x 8 triples x M (4 B); 63
 constexpr int DEC_BLOCK = 512;   // 16 steps of decisions: 64 lanes x 8 B
 constexpr unsigned PK_SPLIT_DEN = 8;  // a sorted table is split between the kernels when < 1/8 of its frames are long
 
+#ifndef VIT_TAB_STATIC
+#define VIT_TAB_STATIC 1  /* one set of table ADDRESSES per table half (even / odd block), the half chosen by a uniform branch: no
+                             address add in front of the table reads (5 per block; 0.4363 -> 0.4306 ms, profiles/r03_ab_tabs.txt) */
+#endif
 struct Lanes {
     u32 toff[5];  // LDS byte offset of this lane's (M,MM) entry for phase rho
 };
@@ -231,7 +235,12 @@ struct Steps {
     static DEV void run(u32& A, u32& B, u32& acc0, u32& acc1, const char* tab, const Lanes& L, u32 lane,
                         const Consts& C) {
         constexpr int RHO = (V + J) % 5;
+#if VIT_TAB_STATIC
+        // L.toff holds LDS addresses of the table half this block reads: no address arithmetic left in the loop
+        const u32 mt = *reinterpret_cast<const __attribute__((address_space(3))) u32*>(L.toff[RHO] + (u32)(J * 64));
+#else
         const u32 mt = *reinterpret_cast<const u32*>(tab + L.toff[RHO] + J * 64);
+#endif
         acs_step<RHO, J, HIST>(A, B, acc0, acc1, mt, lane, C);
         Steps<V, J + 1, JEND, HIST>::run(A, B, acc0, acc1, tab, L, lane, C);
     }
@@ -500,7 +509,9 @@ template <int II, bool REC>
 DEV void tb16_step(u32& PC, u32& cur, const Tb16& L) {
     constexpr int r = II % 5, blk = (6 + II) >> 4, idx = (6 + II) & 15;
     const u32 w = *reinterpret_cast<const __attribute__((address_space(3))) unsigned short*>(PC + (u32)(blk * DEC_BLOCK));
-    const u32 kb = __builtin_amdgcn_ubfe(w, (u32)idx, 1u);
+    // asm: left to itself hipcc narrows the extract of a zero-extended halfword to v_lshrrev_b16 + v_and 1 + v_and 0xffff
+    u32 kb;
+    asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(kb) : "v"(w), "n"(idx));
     const u32 m = (PC >> L.sh[r]) & 4u;
     const u32 t = (kb << L.jj[r]) | m;
     PC = bfi_v(L.mk[r], t, PC);
@@ -658,6 +669,18 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
         const u32 c = (i1 ^ i2 ^ i4) | ((i0 ^ i1 ^ i2) << 1) | ((i0 ^ i3) << 2);  // parity((2i)&poly_j), const.asm:27-63
         L.toff[rho] = pair * 32u + c * 4u;
     }
+#if VIT_TAB_STATIC
+    Lanes L1;
+    {
+        const u32 tb = (u32)(uintptr_t)(const __attribute__((address_space(3))) char*)tab;
+#pragma unroll
+        for (int rho = 0; rho < 5; rho++) {
+            L.toff[rho] += tb;
+            L1.toff[rho] = L.toff[rho] + 1024u;
+            asm volatile("" : "+v"(L1.toff[rho]));  // its own register: as "L + 1024" the ds_read2 pairs would need an add again
+        }
+    }
+#endif
     Consts C;
     C.hi = HI;
     C.rc = renorm_c;
@@ -692,10 +715,20 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
                 sb = load_step<SYM32>(b_sym, tn, tn < b_T);
                 __syncthreads();
             }
+#if VIT_TAB_STATIC
+            if (VIT_STEPS6 && rb + 1u == nb && (T_max & 15u) == 6u) {
+                if (rb & 1u) steps6(v, A, B, acc0, acc1, tab, L1, lane, C);
+                else steps6(v, A, B, acc0, acc1, tab, L, lane, C);
+            } else {
+                if (rb & 1u) steps16<true>(v, A, B, acc0, acc1, tab, L1, lane, C);
+                else steps16<true>(v, A, B, acc0, acc1, tab, L, lane, C);
+            }
+#else
             if (VIT_STEPS6 && rb + 1u == nb && (T_max & 15u) == 6u)
                 steps6(v, A, B, acc0, acc1, tab + (rb & 1u) * 1024u, L, lane, C);
             else
                 steps16<true>(v, A, B, acc0, acc1, tab + (rb & 1u) * 1024u, L, lane, C);
+#endif
             if (rb < R) {
                 r0[rb] = acc0;  // s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off
                 r1[rb] = acc1;
@@ -835,6 +868,18 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
         const u32 c = (i1 ^ i2 ^ i4) | ((i0 ^ i1 ^ i2) << 1) | ((i0 ^ i3) << 2);
         L.toff[rho] = pair * 32u + c * 4u;
     }
+#if VIT_TAB_STATIC
+    Lanes L1;
+    {
+        const u32 tb = (u32)(uintptr_t)(const __attribute__((address_space(3))) char*)tab;
+#pragma unroll
+        for (int rho = 0; rho < 5; rho++) {
+            L.toff[rho] += tb;
+            L1.toff[rho] = L.toff[rho] + 1024u;
+            asm volatile("" : "+v"(L1.toff[rho]));  // its own register: as "L + 1024" the ds_read2 pairs would need an add again
+        }
+    }
+#endif
     Consts C;
     C.hi = HI;
     C.rc = renorm_c;
@@ -909,10 +954,20 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
                     sb = load_step<SYM32>(b_sym, tn, tn < b_T);
                     __syncthreads();
                 }
+#if VIT_TAB_STATIC
+                if (VIT_STEPS6 && rb + 1u == nblk && (T_max & 15u) == 6u) {
+                    if (rb & 1u) steps6(v, A, B, acc0, acc1, tab, L1, lane, C);
+                    else steps6(v, A, B, acc0, acc1, tab, L, lane, C);
+                } else {
+                    if (rb & 1u) steps16<true>(v, A, B, acc0, acc1, tab, L1, lane, C);
+                    else steps16<true>(v, A, B, acc0, acc1, tab, L, lane, C);
+                }
+#else
                 if (VIT_STEPS6 && rb + 1u == nblk && (T_max & 15u) == 6u)
                     steps6(v, A, B, acc0, acc1, tab + (rb & 1u) * 1024u, L, lane, C);
                 else
                     steps16<true>(v, A, B, acc0, acc1, tab + (rb & 1u) * 1024u, L, lane, C);
+#endif
                 if (rb < G) {
                     wspill[(size_t)rb * 64u] = make_uint2(acc1, acc0);  // the order of the LDS blocks: a reload is a plain copy
                 } else {

@@ -86,11 +86,10 @@ struct Lanes {
                           masked DPP moves.  Since the round-2 traceback the kernel sits between the VALU and the LDS limit:
                           none 0.467 ms, bit 3 only 0.458, bit 2 only 0.459, both 0.462 (profiles/r02_ab_k3_swz.txt) */
 #endif
-#ifndef VIT_X01_DPP
-#define VIT_X01_DPP 0
-#endif
 #ifndef VIT_K3
-#define VIT_K3 0
+#define VIT_K3 2  /* the renormalisation subtrahend in three instructions (v_add_u32, v_pk_ashrrev_i16, v_and_or_b32) instead of four
+                     (add, shift, and, multiply-add): no faster in round 2, 0.8 % on the headline batch and 1-2 % on config 3 since the
+                     kernel has fewer instructions elsewhere (profiles/r03_ab_swz_k3.txt) */
 #endif
 #ifndef VIT_STEPS6
 #define VIT_STEPS6 1  /* skip the ten padding steps of the last block when T = 6 mod 16 */
@@ -127,17 +126,10 @@ DEV void exchange(u32& A, u32& B, u32 N0, u32 N1, u32 lane) {
     } else {
         // lane bits 0/1 cannot be masked by DPP bank masks (and DPP needs the source lane active)
         const bool hi = (lane >> P) & 1u;
-#if VIT_X01_DPP
-        // all-lane DPP moves + selects: 16 VALU cycles, but no LDS round trip in the dependency chain
-        constexpr int qp = P == 1 ? 0x4E /*quad_perm:[2,3,0,1]*/ : 0xB1 /*quad_perm:[1,0,3,2]*/;
-        const u32 p1 = __builtin_amdgcn_update_dpp(0u, N1, qp, 0xF, 0xF, true);
-        const u32 p0 = __builtin_amdgcn_update_dpp(0u, N0, qp, 0xF, 0xF, true);
-#else
         // partner values through ds_swizzle (LDS crossbar, no VALU slot): 8 VALU cycles for the selects
         constexpr int pat = 0x1F | ((1 << P) << 10);  // BitMode: src lane = lane ^ 2^P within 32
         const u32 p1 = (u32)__builtin_amdgcn_ds_swizzle((int)N1, pat);
         const u32 p0 = (u32)__builtin_amdgcn_ds_swizzle((int)N0, pat);
-#endif
         A = hi ? p1 : N0;
         B = hi ? N1 : p0;
     }

@@ -18,15 +18,15 @@ with open(os.path.join(src, "bench.json")) as f:
     for line in f:
         if line.startswith("{"):
             bench = json.loads(line)
-with open(os.path.join(dst, "%s_bench.json" % tag), "w") as f:
-    json.dump(bench, f, indent=1)
-lines.append("# %s — bench.py (default flags) on MI355X\n" % tag)
-lines.append("value %.1f %s, ms_per_step %.4f, roofline %s\n" % (bench["value"], bench["unit"], bench["ms_per_step"], json.dumps(bench["roofline"])))
-lines.append("cpu_baseline %s\nparity %s\n" % (json.dumps(bench.get("cpu_baseline")), json.dumps(bench.get("parity"))))
+# (the header lines and profiles/<tag>_bench.json are written at the END: the bench run of a collection precedes its counter
+#  passes, so the counters it attached from profiles/pmc_traffic.json are the previous collection's - they are replaced below
+#  by the ones of THIS collection)
 
 lines.append("\n# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu --no-pipelined   (kernel_stats.csv, top rows; the bench line's `pipelined` leg is left out: its overlapping launches are not what roofline.kernel_ms prices)\n")
 with open(os.path.join(src, "kernel_stats.csv")) as f:
     rows = list(csv.DictReader(f))
+with open(os.path.join(src, "kernel_stats.csv")) as f, open(os.path.join(dst, "%s_kernel_stats_top.csv" % tag), "w") as g:
+    g.writelines(f.readlines()[:9])  # header + the eight kernels with the most time: the same run the summary quotes
 avg_ns = None
 for r in rows[:6]:
     lines.append("%-60.60s calls=%s avg_ns=%s total_ns=%s pct=%s\n" % (r["Name"], r["Calls"], r["AverageNs"], r["TotalDurationNs"], r["Percentage"]))
@@ -119,6 +119,24 @@ if "FETCH_SIZE" in rs_tot and "WRITE_SIZE" in rs_tot and ss.get("roofline"):
 if pmc_json is not None:
     with open(os.path.join(dst, "pmc_traffic.json"), "w") as f:
         json.dump(pmc_json, f, indent=1)
+    # what bench.py's _attach_cached_counters would attach from the file just written
+    r = bench["roofline"]
+    r["traffic"] = pmc_json["hbm_bytes_per_launch"]
+    r["traffic_source"] = "cached from profiles/pmc_traffic.json (%s)" % pmc_json["source"]
+    for k in ("valu_busy", "valu_insts_per_frame_step", "valu_insts_per_wave"):
+        if k in pmc_json:
+            r[k] = pmc_json[k]
+    ss_r = (bench.get("second_stage") or {}).get("roofline")
+    if ss_r and pmc_json.get("second_stage"):
+        ss_r["traffic"] = pmc_json["second_stage"]["hbm_bytes_per_launch"]
+        ss_r["traffic_source"] = r["traffic_source"]
+with open(os.path.join(dst, "%s_bench.json" % tag), "w") as f:
+    json.dump(bench, f, indent=1)
+head = ["# %s — bench.py (default flags) on MI355X; counters in `roofline` = the passes summarised below\n" % tag,
+        "value %.1f %s, ms_per_step %.4f, roofline %s\n" % (bench["value"], bench["unit"], bench["ms_per_step"], json.dumps(bench["roofline"])),
+        "pipelined %s\n" % json.dumps(bench.get("pipelined")),
+        "cpu_baseline %s\nparity %s\n" % (json.dumps(bench.get("cpu_baseline")), json.dumps(bench.get("parity")))]
+lines = head + lines
 vc = int(meta.get("VGPR_Count", 0) or 0)
 lines.append("\n# note on the dispatch columns of rocprofv3's counter CSV: VGPR_Count %d = (granulated_workitem_vgpr_count + 1) * 4,\n"
              "# i.e. the kernel descriptor's %d granules priced at the pre-gfx90a granule of 4; gfx950 allocates in granules of 8, so\n"

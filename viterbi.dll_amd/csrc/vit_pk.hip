@@ -71,6 +71,7 @@ struct Lanes {
     u32 toff[5];  // LDS byte offset of this lane's (M,MM) entry for phase rho
 };
 
+
 // lane-bit <-> register-bit transpose on lane bit J: afterwards A holds the s5=0
 // member and B the s5=1 member of the next butterfly.
 //   A = bit_J(lane) ? N1[lane ^ 2^J] : N0        B = bit_J(lane) ? N1 : N0[lane ^ 2^J]
@@ -103,6 +104,33 @@ struct Lanes {
 // ACS lane roles: which lane bits carry the butterfly index (l5) and which one the pair.
 DEV u32 acs_l5(u32 lane) { return VIT_PAIR_LSB ? lane >> 1 : lane & 31u; }
 DEV u32 acs_pair(u32 lane) { return VIT_PAIR_LSB ? lane & 1u : lane >> 5; }
+// toff by lane, tabulated at compile time (80 VALU instructions per wave as arithmetic; two loads that are back long before the
+// first table read).  Butterfly index of ACS lane l5 at phase rho = rol5(l5, rho); its class = parity((2i) & poly_j), const.asm:27-63.
+struct ToffTable {
+    u32 v[64][8];  // [lane][rho], rows padded to 32 bytes
+};
+constexpr ToffTable make_toff_table() {
+    ToffTable t{};
+    for (u32 lane = 0; lane < 64; lane++) {
+        const u32 l5 = VIT_PAIR_LSB ? lane >> 1 : lane & 31u, pair = VIT_PAIR_LSB ? lane & 1u : lane >> 5;
+        for (u32 rho = 0; rho < 5; rho++) {
+            const u32 i = ((l5 << rho) | (l5 >> (5 - rho))) & 31u;
+            const u32 i0 = i & 1u, i1 = (i >> 1) & 1u, i2 = (i >> 2) & 1u, i3 = (i >> 3) & 1u, i4 = (i >> 4) & 1u;
+            const u32 c = (i1 ^ i2 ^ i4) | ((i0 ^ i1 ^ i2) << 1) | ((i0 ^ i3) << 2);
+            t.v[lane][rho] = pair * 32u + c * 4u;
+        }
+    }
+    return t;
+}
+__constant__ ToffTable g_toff = make_toff_table();
+DEV void load_toff(Lanes& L, u32 lane) {
+    const uint4 a = *reinterpret_cast<const uint4*>(&g_toff.v[lane][0]);
+    L.toff[0] = a.x;
+    L.toff[1] = a.y;
+    L.toff[2] = a.z;
+    L.toff[3] = a.w;
+    L.toff[4] = g_toff.v[lane][4];
+}
 template <int J>  // J = state lane bit (bit J of l5)
 DEV void exchange(u32& A, u32& B, u32 N0, u32 N1, u32 lane) {
     constexpr int P = J + VIT_PAIR_LSB;  // physical lane bit
@@ -651,16 +679,10 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
     const u32 T_max = maxfb + VIT_TAIL;
 
     // ---- ACS lane constants ----
-    const u32 l5 = acs_l5(lane), pair = acs_pair(lane);
+    const u32 l5 = acs_l5(lane);
     const u32 dslot = dec_slot(lane);  // where this lane's history words go inside a decision block
     Lanes L;
-#pragma unroll
-    for (int rho = 0; rho < 5; rho++) {
-        const u32 i = ((l5 << rho) | (l5 >> (5 - rho))) & 31u;  // butterfly index rol5(l, rho)
-        const u32 i0 = i & 1u, i1 = (i >> 1) & 1u, i2 = (i >> 2) & 1u, i3 = (i >> 3) & 1u, i4 = (i >> 4) & 1u;
-        const u32 c = (i1 ^ i2 ^ i4) | ((i0 ^ i1 ^ i2) << 1) | ((i0 ^ i3) << 2);  // parity((2i)&poly_j), const.asm:27-63
-        L.toff[rho] = pair * 32u + c * 4u;
-    }
+    load_toff(L, lane);
 #if VIT_TAB_STATIC
     Lanes L1;
     {
@@ -732,7 +754,8 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
         }
     }
     __syncthreads();
-    for (u32 i = lane; i < 4u * fstride; i += 64u) img[i] = 0;  // the image aliases the dead table region
+#pragma nounroll
+    for (u32 i = lane; i < 4u * fstride; i += 64u) img[i] = 0;  // the image aliases the dead table region (two trips for FIC frames)
 
     // ---- traceback, last part first: lane = (frame fi, block q) ----
     const u32 fi = lane >> 4;
@@ -790,18 +813,25 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
 #endif
     __syncthreads();
 
-    // bit b of the image is decoded bit b; output bytes are MSB-first (deconvolve.cpp:432-433)
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const u32 nbytes = (fbits[k] + 7u) >> 3;  // a partial last byte is padded with zero bits (ChainBack starts from E = 0)
-        uint8_t* o = out + ooff[k];
-        if (((ooff[k] | nbytes) & 3u) == 0) {
-            for (u32 m = lane; m < (nbytes >> 2); m += 64u)
-                reinterpret_cast<u32*>(o)[m] = __builtin_bswap32(__builtin_bitreverse32(img[k * fstride + m]));
+    // bit b of the image is decoded bit b; output bytes are MSB-first (deconvolve.cpp:432-433).  Sixteen lanes per frame,
+    // every lane its dwords m = j, j + 16, ...: two trips for a FIC frame (a loop over the frames with 64 lanes each was
+    // unrolled eightfold by the compiler: 376 VALU instructions per wave for 4 x 96 bytes).
+    {
+        const u32 k = lane >> 4, j = lane & 15u;
+        const u32 fb_k = k == 0 ? fbits[0] : k == 1 ? fbits[1] : k == 2 ? fbits[2] : fbits[3];
+        const size_t oo_k = k == 0 ? ooff[0] : k == 1 ? ooff[1] : k == 2 ? ooff[2] : ooff[3];
+        const u32 nbytes = (fb_k + 7u) >> 3;  // a partial last byte is padded with zero bits (ChainBack starts from E = 0)
+        uint8_t* o = out + oo_k;
+        const u32* im = img + k * fstride;
+        if ((((u32)oo_k | nbytes) & 3u) == 0) {
+#pragma nounroll
+            for (u32 m = j; m < (nbytes >> 2); m += 16u)
+                reinterpret_cast<u32*>(o)[m] = __builtin_bswap32(__builtin_bitreverse32(im[m]));
         } else {
-            for (u32 j = lane; j < nbytes; j += 64u) {
-                const u32 byte = (img[k * fstride + (j >> 2)] >> (8u * (j & 3u))) & 0xFFu;
-                o[j] = (uint8_t)(__builtin_bitreverse32(byte) >> 24);
+#pragma nounroll
+            for (u32 b = j; b < nbytes; b += 16u) {
+                const u32 byte = (im[b >> 2] >> (8u * (b & 3u))) & 0xFFu;
+                o[b] = (uint8_t)(__builtin_bitreverse32(byte) >> 24);
             }
         }
     }
@@ -850,16 +880,10 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
     const bool split = split_gate && (unsigned long long)*split_gate * PK_SPLIT_DEN < (unsigned long long)nframes;
 
     // ---- lane constants (same roles as in vit_pk_kernel) ----
-    const u32 l5 = acs_l5(lane), pair = acs_pair(lane);
+    const u32 l5 = acs_l5(lane);
     const u32 dslot = dec_slot(lane);  // where this lane's history words go inside a decision block
     Lanes L;
-#pragma unroll
-    for (int rho = 0; rho < 5; rho++) {
-        const u32 i = ((l5 << rho) | (l5 >> (5 - rho))) & 31u;
-        const u32 i0 = i & 1u, i1 = (i >> 1) & 1u, i2 = (i >> 2) & 1u, i3 = (i >> 3) & 1u, i4 = (i >> 4) & 1u;
-        const u32 c = (i1 ^ i2 ^ i4) | ((i0 ^ i1 ^ i2) << 1) | ((i0 ^ i3) << 2);
-        L.toff[rho] = pair * 32u + c * 4u;
-    }
+    load_toff(L, lane);
 #if VIT_TAB_STATIC
     Lanes L1;
     {

@@ -607,6 +607,9 @@ DEV u32 traceback_part16(const char* dec, u32* img, u32 fstride, u32 lane, u32 l
 // measured 7-12 % SLOWER on the benchmark batch and is not kept: profiles/r02_ab_persist.txt, r02_ab_stagger.txt,
 // r02_ab_noprio.txt.  Even the loop scaffolding alone (grid = groups, one trip) cost 12 % through the register
 // allocation it led to (128 VGPRs / 104 SGPRs instead of 113 / 63): profiles/r02_ab_r1kernel_vs_loop.txt.
+#ifdef VIT_DIAG_TIMES
+__device__ unsigned long long g_diag_times[16384 * 4];
+#endif
 template <bool SYM32>
 __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict__ sym, uint8_t* __restrict__ out,
                                                         const vit_frame_desc* __restrict__ desc, u32 framebits_uniform,
@@ -615,6 +618,9 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
     // second launch behind the long-frame kernel on a length-sorted table: runs only if that kernel left the short
     // groups to it (same test there, see vit_launch_pk)
     if (split_gate && (unsigned long long)*split_gate * PK_SPLIT_DEN >= (unsigned long long)nframes) return;
+#ifdef VIT_DIAG_TIMES
+    const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();  // s_memtime
+#endif
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* dec = lds;                  // [block - R][lane] -> (acc0, acc1); the last block spills into tab
     char* tab = lds + lay.dec_bytes;  // [tau][pair][c] -> M; after the ACS: last block, scratch, image
@@ -758,6 +764,9 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
     for (u32 i = lane; i < 4u * fstride; i += 64u) img[i] = 0;  // the image aliases the dead table region (two trips for FIC frames)
 
     // ---- traceback, last part first: lane = (frame fi, block q) ----
+#ifdef VIT_DIAG_TIMES
+    const unsigned long long diag_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
     const u32 fi = lane >> 4;
     const u32 t_fb = fi == 0 ? fbits[0] : fi == 1 ? fbits[1] : fi == 2 ? fbits[2] : fbits[3];
     const u32 t_T = t_fb ? t_fb + VIT_TAIL : 0u;  // steps of this lane's frame
@@ -813,6 +822,16 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
 #endif
     __syncthreads();
 
+#ifdef VIT_DIAG_TIMES
+    if (threadIdx.x == 0 && blockIdx.x < 16384u) {  // timeline diagnostic: start, start of the traceback, end, hardware slot
+        u32 hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        g_diag_times[blockIdx.x * 4u + 0u] = diag_t0;
+        g_diag_times[blockIdx.x * 4u + 1u] = diag_t1;
+        g_diag_times[blockIdx.x * 4u + 2u] = __builtin_amdgcn_s_memrealtime();
+        g_diag_times[blockIdx.x * 4u + 3u] = hwid;
+    }
+#endif
     // bit b of the image is decoded bit b; output bytes are MSB-first (deconvolve.cpp:432-433).  Sixteen lanes per frame,
     // every lane its dwords m = j, j + 16, ...: two trips for a FIC frame (a loop over the frames with 64 lanes each was
     // unrolled eightfold by the compiler: 376 VALU instructions per wave for 4 x 96 bytes).
@@ -1092,6 +1111,11 @@ constexpr u32 PK_SHORT_MAX = SEG_BLOCKS * 16u - VIT_TAIL;  // 778: the longest f
 
 }  // namespace
 
+#ifdef VIT_DIAG_TIMES
+extern "C" __attribute__((visibility("default"))) int vit_diag_times(void* host_buf) {
+    return (int)hipMemcpyFromSymbol(host_buf, HIP_SYMBOL(g_diag_times), sizeof(unsigned long long) * 16384 * 4);
+}
+#endif
 bool vit_pk_supported(uint32_t max_framebits) {
     if (max_framebits < 2 || max_framebits > PK_MAX_FRAMEBITS || (max_framebits % 2u) != 0) return false;
     const u32 nblk = (max_framebits + VIT_TAIL + 15u) >> 4;

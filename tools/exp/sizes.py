@@ -17,7 +17,10 @@ def timeit(fn, steps=20):
     for _ in range(steps): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / steps
-for fb, n in ((768, 65536), (768, 16384), (3072, 16384), (3072, 81920), (6912, 7280), (6912, 36400)):
+CASES = ((768, 65536), (768, 16384), (3072, 16384), (3072, 81920), (6912, 7280), (6912, 36400))
+if os.environ.get("SIZES"):  # e.g. SIZES=3072:81920,6912:36400
+    CASES = tuple(tuple(int(x) for x in c.split(":")) for c in os.environ["SIZES"].split(","))
+for fb, n in CASES:
     sym = make_frames(n, fb, seed=fb, device=dev)
     out = torch.zeros((n, fb // 8), dtype=torch.uint8, device=dev)
     ms = timeit(lambda: V.decode_batch_dev(sym, out, fb, n))

@@ -1,5 +1,5 @@
 """Per-wave timeline of one launch of the headline batch (diagnostic build -DVIT_DIAG_TIMES): start, traceback start and end
-of every workgroup (s_memtime, 100 MHz) -> rounds, spread, drain.  usage: python tools/exp/timeline.py [frames] [noisy|random]"""
+of every workgroup (s_memtime, 100 MHz) -> rounds, spread, drain.  usage: python tools/exp/timeline.py [frames] [noisy|random] [framebits]"""
 import ctypes, json, os, sys
 import numpy as np, torch
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -12,13 +12,13 @@ lib = ctypes.CDLL(os.environ["VITERBI_AMD_LIB"])
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 kind = sys.argv[2] if len(sys.argv) > 2 else "noisy"
 dev = torch.device("cuda", 0)
-fb = 768
+fb = int(sys.argv[3]) if len(sys.argv) > 3 else 768
 if kind == "noisy":
     sym = make_frames(frames, fb, seed=3, device=dev)
 else:
     sym = torch.randint(0, 256, (frames, 4 * (fb + 6)), dtype=torch.uint8, device=dev)
 out = torch.zeros((frames, fb // 8), dtype=torch.uint8, device=dev)
-for _ in range(200):
+for _ in range(40):
     V.decode_batch_dev(sym, out, fb, frames)
 torch.cuda.synchronize()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -927,11 +927,49 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
         for (int k = 0; k < 4; k++) sel[k] = hb | (0x00040000u + 0x00010001u * k);
     }
 
+#ifndef VIT_LONG_FIRST_STATIC
+#define VIT_LONG_FIRST_STATIC 1
+#endif
+#ifndef VIT_LONG_ROT
+#define VIT_LONG_ROT 2  /* 0: no issue priorities in this kernel, 2: rotating priorities in a one-round launch, 1: in the last round of every launch */
+#endif
+#if VIT_LONG_ROT
+    u32 prio_slot;
+    {
+        u32 hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        prio_slot = hwid & 3u;  // wave slot within the SIMD
+    }
+    // A launch with no more groups than workgroups is ONE round of waves: nothing takes the place of a wave that is done, and the
+    // hardware's arbitration lets the four waves of a SIMD finish one after the other (profiles/r03_timeline.jsonl: at 320, 385,
+    // 450 and 550 us of a 558 us launch), i.e. the SIMD runs on three, two, one wave for the second half.  An issue priority that
+    // rotates block by block gives every wave the same share, and they finish together: 16384 x 3072 bits 0.561 -> 0.473 ms,
+    // 16384 x 4608 bits 0.812 -> 0.700 (profiles/r03_ab_long_oneround.txt).  Doing the same for the LAST round of a longer launch
+    // (VIT_LONG_ROT = 1: the groups from ngroups - gridDim.x on) measured worse than leaving multi-round launches alone.
+#endif
+    bool first_group = true;
     for (;;) {
         u32 grp = 0;
+#if VIT_LONG_FIRST_STATIC
+        // a workgroup's first group is its own index; only the later ones come from the counter (4096 workgroups that start
+        // with an atomic on one address are served one at a time: the last one waited 46 us, profiles/r03_timeline.jsonl).
+        // Worth 3-7 % on most multi-round shapes and on config 3; launches of an exact number of rounds lose 2-3 % (the
+        // staggered start had kept their rounds apart): profiles/r03_ab_long_oneround.txt
+        if (first_group) {
+            grp = blockIdx.x;
+        } else {
+            if (lane == 0) grp = gridDim.x + atomicAdd(counter, 1u);
+            grp = (u32)__builtin_amdgcn_readfirstlane((int)grp);
+        }
+        first_group = false;
+#else
         if (lane == 0) grp = atomicAdd(counter, 1u);
         grp = (u32)__builtin_amdgcn_readfirstlane((int)grp);
+#endif
         if (grp >= ngroups) break;
+#ifdef VIT_DIAG_TIMES
+        const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
         const long long f0 = (long long)grp * 4;
         u32 fbits[4];
         size_t soff[4], ooff[4];
@@ -981,6 +1019,16 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
             auto sa = load_step<SYM32>(a_sym, tau, tau < a_T), sb = load_step<SYM32>(b_sym, tau, tau < b_T);
             u32 v = 0;
             for (u32 rb = 0; rb < nblk; rb++) {
+#if VIT_LONG_ROT
+                if (VIT_LONG_ROT == 2 ? ngroups <= gridDim.x : grp + gridDim.x >= ngroups) {
+                    switch ((prio_slot + rb) & 3u) {
+                        case 0: __builtin_amdgcn_s_setprio(0); break;
+                        case 1: __builtin_amdgcn_s_setprio(1); break;
+                        case 2: __builtin_amdgcn_s_setprio(2); break;
+                        default: __builtin_amdgcn_s_setprio(3); break;
+                    }
+                }
+#endif
                 if ((rb & 1u) == 0) {
                     __syncthreads();
                     prepass(pack_step(sa), pack_step(sb), tab, lane, sel);
@@ -1014,6 +1062,9 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
         }
         __syncthreads();
         img[lane] = 0;  // 4 frames x IMG_RING words (the ring aliases the dead table region)
+#ifdef VIT_DIAG_TIMES
+        const unsigned long long diag_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
         // ---- traceback: LDS tail, then the spilled blocks 16 at a time from the top ----
         const u32 fi = lane >> 4, slot = lane & (IMG_RING - 1u);
@@ -1081,6 +1132,16 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
                 hi = lo;
             }
             __syncthreads();
+#ifdef VIT_DIAG_TIMES
+            if (lane == 0 && grp < 16384u) {
+                u32 hwid;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+                g_diag_times[grp * 4u + 0u] = diag_t0;
+                g_diag_times[grp * 4u + 1u] = diag_t1;
+                g_diag_times[grp * 4u + 2u] = __builtin_amdgcn_s_memrealtime();
+                g_diag_times[grp * 4u + 3u] = hwid;
+            }
+#endif
             continue;
         }
 #endif

@@ -322,11 +322,13 @@ struct PkLayout {
     u32 img_off;    // output bit image
     u32 total;
     u32 maxfb;      // the framebits this layout was sized for
+    u32 resident;   // workgroups of this size the device holds at once (set by the launcher; 0 = unknown)
 };
 __host__ __device__ inline PkLayout pk_layout(u32 maxfb) {  // single-segment kernel (nblk <= 49)
     const u32 nb = (maxfb + VIT_TAIL + 15u) >> 4;
     PkLayout l;
     l.maxfb = maxfb;
+    l.resident = 0;
     l.dec_bytes = (nb - pk_reg_blocks(nb) - 1u) * DEC_BLOCK;
     const u32 scratch = 64u * 4u * pk_scratch_words(maxfb), img = 16u * pk_img_stride(maxfb);
     u32 tabregion = DEC_BLOCK + scratch + img;  // the image lives in the dead table region too
@@ -627,12 +629,22 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
     u32* img = reinterpret_cast<u32*>(lds + lay.img_off);  // output bit image, 4 frames
     const u32 lane = threadIdx.x;
     const long long f0 = (long long)blockIdx.x * 4;
+#ifndef VIT_SHORT_ROT
+#define VIT_SHORT_ROT 0
+#endif
+#if VIT_SHORT_ROT
+    u32 prio_slot = 0;
+    const bool rot_active = lay.resident != 0 && (VIT_SHORT_ROT == 2 ? gridDim.x <= lay.resident : blockIdx.x + lay.resident >= gridDim.x);
+#endif
 #if VIT_PRIO
     // Stagger the waves that share a SIMD: different issue priorities make them drift apart, so the
     // latency-bound traceback of one overlaps the ACS of the others instead of all four hitting it together.
     {
         u32 hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+#if VIT_SHORT_ROT
+        prio_slot = hwid & 3u;
+#endif
 #ifdef VIT_PRIO_FIRST
         if (blockIdx.x < VIT_PRIO_FIRST)  // experiment: priorities only for the waves of the first round
 #endif
@@ -727,6 +739,16 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
         auto sa = load_step<SYM32>(a_sym, tau, tau < a_T), sb = load_step<SYM32>(b_sym, tau, tau < b_T);
         u32 v = 0;
         for (u32 rb = 0; rb < nb; rb++) {
+#if VIT_SHORT_ROT
+            if (rot_active) {  // experiment: see the long-frame kernel's rotating priorities
+                switch ((prio_slot + rb) & 3u) {
+                    case 0: __builtin_amdgcn_s_setprio(0); break;
+                    case 1: __builtin_amdgcn_s_setprio(1); break;
+                    case 2: __builtin_amdgcn_s_setprio(2); break;
+                    default: __builtin_amdgcn_s_setprio(3); break;
+                }
+            }
+#endif
             if ((rb & 1u) == 0) {
                 __syncthreads();  // every lane is done with the previous table
                 prepass(pack_step(sa), pack_step(sb), tab, lane, sel);
@@ -872,6 +894,7 @@ constexpr u32 IMG_RING = 16;  // output bit image of the long-frame kernel: a ri
 __host__ __device__ inline PkLayout pk_layout_long(u32 maxfb) {
     PkLayout l;
     l.maxfb = maxfb;
+    l.resident = 0;
     l.dec_bytes = DUMP_GROUP * DEC_BLOCK;
     const u32 scratch = 64u * 4u * pk_scratch_words(maxfb), img = 4u * 4u * IMG_RING;
     u32 tabregion = DEC_BLOCK + scratch + img;
@@ -1251,7 +1274,12 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
     const bool is_long = nblk > SEG_BLOCKS;
 #endif
     const bool sort = d_desc != nullptr && nframes >= SORT_MIN_FRAMES && sort_enabled();
-    const PkLayout lay = is_long ? pk_layout_long(max_framebits) : pk_layout(max_framebits);
+    PkLayout lay = is_long ? pk_layout_long(max_framebits) : pk_layout(max_framebits);
+    {
+        u32 per_cu = (160u * 1024u) / lay.total;
+        if (per_cu > 16u) per_cu = 16u;  // 4 waves per SIMD (launch bounds)
+        lay.resident = per_cu * (u32)vit_device_cus(dev);
+    }
     long long grid = groups;
     if (is_long) {  // the long-frame kernel is persistent: as many workgroups as fit the chip
         u32 per_cu = (160u * 1024u) / lay.total;

@@ -322,13 +322,11 @@ struct PkLayout {
     u32 img_off;    // output bit image
     u32 total;
     u32 maxfb;      // the framebits this layout was sized for
-    u32 resident;   // workgroups of this size the device holds at once (set by the launcher; 0 = unknown)
 };
 __host__ __device__ inline PkLayout pk_layout(u32 maxfb) {  // single-segment kernel (nblk <= 49)
     const u32 nb = (maxfb + VIT_TAIL + 15u) >> 4;
     PkLayout l;
     l.maxfb = maxfb;
-    l.resident = 0;
     l.dec_bytes = (nb - pk_reg_blocks(nb) - 1u) * DEC_BLOCK;
     const u32 scratch = 64u * 4u * pk_scratch_words(maxfb), img = 16u * pk_img_stride(maxfb);
     u32 tabregion = DEC_BLOCK + scratch + img;  // the image lives in the dead table region too
@@ -612,7 +610,12 @@ DEV u32 traceback_part16(const char* dec, u32* img, u32 fstride, u32 lane, u32 l
 #ifdef VIT_DIAG_TIMES
 __device__ unsigned long long g_diag_times[16384 * 4];
 #endif
-template <bool SYM32>
+// ROT: a launch of ONE round of waves (no more workgroups than the device holds at once): nothing takes the place of a wave that
+// is done, so the static per-slot priorities - under which a wave takes between 63 and 248 us - would leave the second half of the
+// launch to ever fewer waves; the priority rotates block by block instead and the four waves of a SIMD finish together
+// (16384 FIC frames: 0.130 -> 0.117 ms).  A separate instantiation: the rotation's test inside the block loop cost launches that
+// do not use it up to 6 % (profiles/r03_ab_long_oneround.txt).
+template <bool SYM32, bool ROT>
 __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict__ sym, uint8_t* __restrict__ out,
                                                         const vit_frame_desc* __restrict__ desc, u32 framebits_uniform,
                                                         long long nframes, PkLayout lay, u32 vmax,
@@ -629,22 +632,14 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
     u32* img = reinterpret_cast<u32*>(lds + lay.img_off);  // output bit image, 4 frames
     const u32 lane = threadIdx.x;
     const long long f0 = (long long)blockIdx.x * 4;
-#ifndef VIT_SHORT_ROT
-#define VIT_SHORT_ROT 0
-#endif
-#if VIT_SHORT_ROT
     u32 prio_slot = 0;
-    const bool rot_active = lay.resident != 0 && (VIT_SHORT_ROT == 2 ? gridDim.x <= lay.resident : blockIdx.x + lay.resident >= gridDim.x);
-#endif
 #if VIT_PRIO
     // Stagger the waves that share a SIMD: different issue priorities make them drift apart, so the
     // latency-bound traceback of one overlaps the ACS of the others instead of all four hitting it together.
     {
         u32 hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-#if VIT_SHORT_ROT
         prio_slot = hwid & 3u;
-#endif
 #ifdef VIT_PRIO_FIRST
         if (blockIdx.x < VIT_PRIO_FIRST)  // experiment: priorities only for the waves of the first round
 #endif
@@ -739,8 +734,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
         auto sa = load_step<SYM32>(a_sym, tau, tau < a_T), sb = load_step<SYM32>(b_sym, tau, tau < b_T);
         u32 v = 0;
         for (u32 rb = 0; rb < nb; rb++) {
-#if VIT_SHORT_ROT
-            if (rot_active) {  // experiment: see the long-frame kernel's rotating priorities
+            if constexpr (ROT) {
                 switch ((prio_slot + rb) & 3u) {
                     case 0: __builtin_amdgcn_s_setprio(0); break;
                     case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -748,7 +742,6 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
                     default: __builtin_amdgcn_s_setprio(3); break;
                 }
             }
-#endif
             if ((rb & 1u) == 0) {
                 __syncthreads();  // every lane is done with the previous table
                 prepass(pack_step(sa), pack_step(sb), tab, lane, sel);
@@ -894,7 +887,6 @@ constexpr u32 IMG_RING = 16;  // output bit image of the long-frame kernel: a ri
 __host__ __device__ inline PkLayout pk_layout_long(u32 maxfb) {
     PkLayout l;
     l.maxfb = maxfb;
-    l.resident = 0;
     l.dec_bytes = DUMP_GROUP * DEC_BLOCK;
     const u32 scratch = 64u * 4u * pk_scratch_words(maxfb), img = 4u * 4u * IMG_RING;
     u32 tabregion = DEC_BLOCK + scratch + img;
@@ -1259,11 +1251,13 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
     if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
     {  // the dynamic-LDS opt-in is per device
         static uint64_t optin_done = 0;
-        const void* ks[4] = {reinterpret_cast<const void*>(vit_pk_kernel<false>),
-                             reinterpret_cast<const void*>(vit_pk_kernel<true>),
+        const void* ks[6] = {reinterpret_cast<const void*>(vit_pk_kernel<false, false>),
+                             reinterpret_cast<const void*>(vit_pk_kernel<true, false>),
+                             reinterpret_cast<const void*>(vit_pk_kernel<false, true>),
+                             reinterpret_cast<const void*>(vit_pk_kernel<true, true>),
                              reinterpret_cast<const void*>(vit_pk_long_kernel<false>),
                              reinterpret_cast<const void*>(vit_pk_long_kernel<true>)};
-        if ((e = vit_optin_dynamic_lds(ks, 4, 160 * 1024, dev, &optin_done)) != hipSuccess) return e;
+        if ((e = vit_optin_dynamic_lds(ks, 6, 160 * 1024, dev, &optin_done)) != hipSuccess) return e;
     }
     const long long groups = (nframes + 3) / 4;
     if (groups > 0x7FFFFFFFLL) return hipErrorInvalidValue;
@@ -1274,12 +1268,7 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
     const bool is_long = nblk > SEG_BLOCKS;
 #endif
     const bool sort = d_desc != nullptr && nframes >= SORT_MIN_FRAMES && sort_enabled();
-    PkLayout lay = is_long ? pk_layout_long(max_framebits) : pk_layout(max_framebits);
-    {
-        u32 per_cu = (160u * 1024u) / lay.total;
-        if (per_cu > 16u) per_cu = 16u;  // 4 waves per SIMD (launch bounds)
-        lay.resident = per_cu * (u32)vit_device_cus(dev);
-    }
+    const PkLayout lay = is_long ? pk_layout_long(max_framebits) : pk_layout(max_framebits);
     long long grid = groups;
     if (is_long) {  // the long-frame kernel is persistent: as many workgroups as fit the chip
         u32 per_cu = (160u * 1024u) / lay.total;
@@ -1288,13 +1277,25 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
         if (grid > groups) grid = groups;
     }
     const bool need_counter = is_long;
+    // single-segment kernel: the instantiation with rotating priorities for a launch of one round of waves
+    auto launch_short = [&](long long g, const PkLayout& l, u32 vmax, const unsigned* gate, bool may_rotate) {
+        u32 per_cu = (160u * 1024u) / l.total;
+        if (per_cu > 16u) per_cu = 16u;  // 4 waves per SIMD (launch bounds)
+        const bool rot = may_rotate && g <= (long long)per_cu * vit_device_cus(dev);
+#define VIT_LAUNCH_SHORT(S32, R)                                                                                          \
+    hipLaunchKernelGGL((vit_pk_kernel<S32, R>), dim3((unsigned)g), dim3(64), l.total, stream, d_sym, d_out, d_desc, framebits, \
+                       (long long)nframes, l, vmax, gate, rc)
+        if (sym32) {
+            if (rot) VIT_LAUNCH_SHORT(true, true);
+            else VIT_LAUNCH_SHORT(true, false);
+        } else {
+            if (rot) VIT_LAUNCH_SHORT(false, true);
+            else VIT_LAUNCH_SHORT(false, false);
+        }
+#undef VIT_LAUNCH_SHORT
+    };
     if (!need_counter && !sort) {
-        if (sym32)
-            hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
-                               d_desc, framebits, (long long)nframes, lay, lay.maxfb, (const unsigned*)nullptr, rc);
-        else
-            hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
-                               d_desc, framebits, (long long)nframes, lay, lay.maxfb, (const unsigned*)nullptr, rc);
+        launch_short(grid, lay, lay.maxfb, nullptr, true);
         return hipGetLastError();
     }
     const u32 spill_blocks = is_long ? nblk - LONG_LDS_BLOCKS : 0u;
@@ -1357,23 +1358,14 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
                                short_max, gate, rc);
         if (short_max && (e = hipGetLastError()) == hipSuccess) {
             const PkLayout lsh = pk_layout(PK_SHORT_MAX);
-            if (sym32)
-                hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)groups), dim3(64), lsh.total, stream, d_sym, d_out,
-                                   d_desc, framebits, (long long)nframes, lsh, max_framebits, gate, rc);
-            else
-                hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)groups), dim3(64), lsh.total, stream, d_sym, d_out,
-                                   d_desc, framebits, (long long)nframes, lsh, max_framebits, gate, rc);
+            launch_short(groups, lsh, max_framebits, gate, false);  // shares the chip with the long-frame kernel: static priorities
             // join: whatever the caller enqueues next waits for both kernels
             if ((e = hipGetLastError()) != hipSuccess) return e;
             if ((e = hipEventRecord(sc.ev_join, sc.side)) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(stream, sc.ev_join, 0)) != hipSuccess) return e;
         }
-    } else if (sym32) {
-        hipLaunchKernelGGL(vit_pk_kernel<true>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
-                           d_desc, framebits, (long long)nframes, lay, lay.maxfb, (const unsigned*)nullptr, rc);
     } else {
-        hipLaunchKernelGGL(vit_pk_kernel<false>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out,
-                           d_desc, framebits, (long long)nframes, lay, lay.maxfb, (const unsigned*)nullptr, rc);
+        launch_short(grid, lay, lay.maxfb, nullptr, true);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     return hipEventRecord(sc.ev, stream);

@@ -733,7 +733,38 @@ __global__ __launch_bounds__(RS_THREADS, 4) void rs_kernel(const uint8_t* __rest
     };
     if (pre_ok && (long long)blockIdx.x < ngroups) prefetch(blockIdx.x);
 
+#ifndef RS_PRIO_ROT
+#define RS_PRIO_ROT 1
+#endif
+#if RS_PRIO_ROT
+    // Issue priority that rotates pass by pass (see vit_pk.hip: the hardware's arbitration otherwise lets the waves of a SIMD - here
+    // one of each of the CU's four workgroups - advance one after the other): -3 % on clean data, -6 % with errors in 6 % of the columns
+    // (profiles/r03_ab_rs_lfsr2.txt).  RS_PRIO_ROT = 2: the four waves of a workgroup share the level (the slot of wave 0).
+    uint32_t rs_slot, rs_pass = 0;
+    {
+        uint32_t hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        rs_slot = hwid & 3u;
+#if RS_PRIO_ROT == 2
+        __shared__ uint32_t s_slot;
+        if (tid == 0) s_slot = rs_slot;
+        __syncthreads();
+        rs_slot = s_slot;
+        rs_slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)rs_slot);
+#endif
+    }
+#endif
     for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+#if RS_PRIO_ROT
+        if (ngroups > 2 * (long long)gridDim.x)  // a launch of one or two passes has nothing to level (and measured 2 % slower with it)
+        switch ((rs_slot + rs_pass) & 3u) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+        rs_pass++;
+#endif
         const long long sf0 = g * spb;
         const uint32_t nloc = nsf - sf0 < (long long)spb ? (uint32_t)(nsf - sf0) : spb;
         if (tid < spb) {

@@ -44,6 +44,14 @@
 // long frames of a multiple of 16 bits - every DAB size -: 16-step blocks in
 // straight-line code, 5 instead of 9 instructions per step back (traceback_part16).
 //
+// Scheduling (round 3, from a per-workgroup timeline of the launch, tools/exp/timeline.py): the hardware's arbitration lets the
+// waves of a SIMD advance one after the other.  In a launch of many rounds of waves that is welcome - the latency-bound traceback
+// of one wave runs under the ACS of the others - and ONE wave per SIMD at a lower static issue priority is the best of eight
+// maps measured (four distinct levels starve the lowest: 63 ... 248 us per wave and a 50 us drain).  In a launch of ONE round
+// nothing replaces a finished wave, so the priority rotates block by block and the four waves finish together (a separate
+// instantiation of the single-segment kernel; a run-time branch in the persistent long-frame kernel, whose workgroups also take
+// their first group statically instead of queueing at one atomic counter).
+//
 // Instruction costs that shaped this (profiles/r01_valu_issue_rates_ubench.txt): v_pk_*,
 // VOP3 three-operand, DPP, SDWA, v_cmp = 4 cycles per wave; plain VOP2 = 2;
 // v_permlane*_swap = 8; v_cndmask_b32 via VCC ~22; SALU 1 instr/cycle/CU.

@@ -77,6 +77,23 @@ def test_fast_traceback_form_every_multiple_of_16(V, O, torch_cuda):
         assert np.array_equal(got, want), "framebits=%d" % fb
 
 
+@pytest.mark.parametrize("extra_groups", [0, 3, 4097])
+def test_launch_shapes_around_one_round_of_waves(V, O, torch_cuda, extra_groups):
+    """Launches of exactly / just over one round of resident workgroups: the single-segment kernel switches between its two
+    instantiations (rotating issue priority for one round of waves), the persistent long-frame kernel hands every workgroup its
+    first group statically and the later ones from the counter.  Every output byte of every frame is compared."""
+    resident = 16 * torch_cuda.cuda.get_device_properties(0).multi_processor_count  # 10 KB of LDS per workgroup: 16 per CU
+    for fb, seed in ((96, 41), (784, 42)):  # 96 bits: single-segment kernel; 784: the shortest frames of the long-frame kernel
+        n = 4 * (resident + extra_groups) - (1 if extra_groups == 3 else 0)  # once with a ragged last group
+        base = _mixed_input(O, 512, fb, seed=seed)
+        reps = (n + 511) // 512
+        sym = np.tile(base, (reps, 1))[:n]
+        want = np.tile(O.decode_batch(fb, base, nthreads=8), (reps, 1))[:n]
+        got = _gpu_decode(V, torch_cuda, sym, fb, 2)
+        bad = int((got != want).any(axis=1).sum())
+        assert got.shape == want.shape and bad == 0, "framebits %d, %d groups: %d frames differ" % (fb, (n + 3) // 4, bad)
+
+
 def test_auto_kernel_handles_max_length(V, O, torch_cuda):
     framebits, n = 9216, 5
     sym = _mixed_input(O, n, framebits, seed=5)

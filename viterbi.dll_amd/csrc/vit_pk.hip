@@ -589,7 +589,8 @@ DEV u32 traceback_part16(const char* dec, u32* img, u32 fstride, u32 lane, u32 l
         P_out = P & 0x1FFu;
     }
     for (int pass = 0; pass < 17; pass++) {
-        const u32 nxt = __shfl_down(P_out, 1);
+        // the block above = the next lane of the same 16-lane row: one DPP move (row_shl:1), no LDS round trip in the pass loop
+        const u32 nxt = (u32)__builtin_amdgcn_update_dpp(0, (int)P_out, 0x101, 0xF, 0xF, true);
         const u32 new_in = (q + 1u < nl) ? nxt : PC_top;
         const bool changed = has_work && !fixed && new_in != P_in;
         if (!__any(changed)) break;

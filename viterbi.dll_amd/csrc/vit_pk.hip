@@ -969,6 +969,14 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         prio_slot = hwid & 3u;  // wave slot within the SIMD
     }
+#ifndef VIT_LONG_BASE_PRIO
+#define VIT_LONG_BASE_PRIO 1
+#endif
+#if VIT_LONG_BASE_PRIO
+    // every wave of this kernel at the level of the single-segment kernel's three regular waves: when a split table runs both kernels
+    // side by side, the few long groups are the critical path and must not rank below the other kernel's waves
+    __builtin_amdgcn_s_setprio(1);
+#endif
     // A launch with no more groups than workgroups is ONE round of waves: nothing takes the place of a wave that is done, and the
     // hardware's arbitration lets the four waves of a SIMD finish one after the other (profiles/r03_timeline.jsonl: at 320, 385,
     // 450 and 550 us of a 558 us launch), i.e. the SIMD runs on three, two, one wave for the second half.  An issue priority that

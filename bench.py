@@ -169,7 +169,7 @@ def rs_test_block(nsf, rsdims, p_err, seed):
     return to_block(bad, 120), to_block(cw[:110], 110), err.reshape(nsf, rsdims).sum(axis=1).astype(np.int32)
 
 
-def second_stage(V, dev, nsf=131072, rsdims=24, distinct=256, iters=10):
+def second_stage(V, dev, nsf=131072, rsdims=24, distinct=256, iters=100):
     p, want_out, want_ret = rs_test_block(distinct, rsdims, 0.06, seed=4242)
     reps = nsf // distinct
     d_p = torch.from_numpy(p).to(dev).repeat(reps, 1).contiguous()
@@ -197,29 +197,85 @@ def second_stage(V, dev, nsf=131072, rsdims=24, distinct=256, iters=10):
             "outputs_and_return_values_as_constructed": ok}
 
 
-def pipelined_leg(V, d_sym, d_out, steps):
-    """The same K steps with consecutive launches ALTERNATING BETWEEN TWO HIP STREAMS (two output buffers): while one launch
-    drains, the next one already fills the chip, so the fixed ~36 us a launch of this kernel spends ramping up and draining
-    (9 % of the 65536-frame batch, profiles/r03_scale_n.jsonl) overlap with useful work.  What a host that streams batch after
-    batch gets; reported NEXT TO `value`, which stays the one-stream figure of rounds 1-2 (whose kernel duration is what the
-    roofline object and the rocprof summary price)."""
+def precondition(launch, ms=150.0):
+    """untimed: ~15 ms of sustained load bring the MI355X to its steady-state clocks; a leg that follows seconds of
+    GPU idle (the CPU baseline) starts ~10 % slow without it (tools/exp/trend.py)"""
+    t_end = time.perf_counter() + ms / 1e3
+    k = 0
+    while time.perf_counter() < t_end:
+        for _ in range(8):
+            launch(k)
+            k += 1
+        torch.cuda.synchronize()
+
+
+def pipelined_leg(V, d_sym, d_out, launches=400):
+    """`launches` steps (a fixed count, whatever --steps is) with consecutive launches ALTERNATING BETWEEN TWO HIP STREAMS
+    (two output buffers): while one launch drains, the next one already fills the chip, so the fixed ~20 us a launch of
+    this kernel spends ramping up and draining overlap with useful work.  What a host that streams batch after batch
+    gets; reported NEXT TO `value`, which stays the one-stream figure (whose kernel duration is what the roofline
+    object and the rocprof summary price).  Timed with HIP events on BOTH streams: start = one event both streams wait
+    for, end = the later of the two streams' last launches."""
     n = d_sym.shape[0]
     outs = [d_out, torch.zeros_like(d_out)]
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-    torch.cuda.synchronize()
-    for k in range(16):  # both streams warm
+
+    def launch(k):
         V.decode_batch_dev(d_sym, outs[k & 1], FRAMEBITS, n, stream=streams[k & 1].cuda_stream)
+
     torch.cuda.synchronize()
+    precondition(launch)
+    e0 = torch.cuda.Event(enable_timing=True)
+    ends = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+    e0.record(streams[0])
+    streams[1].wait_event(e0)
     t0 = time.perf_counter()
-    for k in range(steps):
-        V.decode_batch_dev(d_sym, outs[k & 1], FRAMEBITS, n, stream=streams[k & 1].cuda_stream)
+    for k in range(launches):
+        launch(k)
+    ends[0].record(streams[0])
+    ends[1].record(streams[1])
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    host_ms = (time.perf_counter() - t0) * 1e3
+    ms = max(e0.elapsed_time(ends[0]), e0.elapsed_time(ends[1]))
     same = bool(torch.equal(outs[0], outs[1]))
-    return {"streams": 2, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
-            "value": round(n * FRAMEBITS * steps / dt / 1e6, 1) if same else 0.0, "unit": "Mbit/s",
-            "both_output_buffers_equal": same,
+    return {"streams": 2, "steps": launches, "ms_per_step": round(ms / launches, 4),
+            "value": round(n * FRAMEBITS * launches / (ms * 1e-3) / 1e6, 1) if same else 0.0, "unit": "Mbit/s",
+            "timing": "HIP events on both streams (host clock over the same launches: %.4f ms per step)" % (host_ms / launches),
+            "preconditioned_ms": 150.0, "both_output_buffers_equal": same,
             "what": "consecutive launches alternate between two HIP streams: ramp and drain of neighbouring launches overlap"}
+
+
+def input_sensitivity(V, O, dev, n, seed, ge, launches=300):
+    """The traceback is the one input-dependent part of the kernel: the same batch shape at Eb/N0 = 0 dB and on uniform
+    random bytes (no signal at all: the worst case), `launches` launches each behind their own pre-conditioning, HIP
+    events on the launch stream; every frame compared with the oracle AFTER the timed region (O = None: not checked)."""
+    out = {}
+    for name in ("0dB", "random_bytes"):
+        if name == "0dB":
+            d_sym = make_frames(n, FRAMEBITS, seed=seed + 17, device=dev, ebn0_db=0.0)
+        else:
+            g = torch.Generator(device=dev)
+            g.manual_seed(seed + 29)
+            d_sym = torch.randint(0, 256, (n, 4 * (FRAMEBITS + TAIL)), generator=g, dtype=torch.uint8, device=dev)
+        d_out = torch.zeros((n, (FRAMEBITS + 7) // 8), dtype=torch.uint8, device=dev)
+        precondition(lambda k: V.decode_batch_dev(d_sym, d_out, FRAMEBITS, n))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(launches):
+            V.decode_batch_dev(d_sym, d_out, FRAMEBITS, n)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / launches
+        rec = {"ms_per_step": round(ms, 4), "value": round(n * FRAMEBITS / (ms * 1e-3) / 1e6, 1), "launches": launches}
+        if O is not None:
+            ref = O.decode_batch(FRAMEBITS, d_sym.cpu().numpy(), nthreads=len(os.sched_getaffinity(0)), ge=bool(ge))
+            bad = int((d_out.cpu().numpy() != ref).any(axis=1).sum())
+            rec["frames_checked"], rec["frames_differing"] = n, bad
+            if bad:
+                rec["value"] = 0.0
+        out[name] = rec
+        del d_sym, d_out
+    return out
 
 
 def parse_args(argv=None):
@@ -240,6 +296,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-rs", action="store_true", help="skip the second-stage (RScheckSuperframe batch) measurement")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-stream leg (`pipelined` in the JSON line)")
+    ap.add_argument("--no-sensitivity", action="store_true",
+                    help="skip the input-family leg (`input_sensitivity`: the same batch at 0 dB and on uniform random bytes)")
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
                     help="untimed GPU pre-conditioning before the W warm-up steps: the MI355X needs ~15 ms of sustained load "
                          "to reach its steady-state clocks (first launches run ~10 %% slower, tools/exp/trend.py)")
@@ -562,11 +620,21 @@ def main(argv=None):
                 result["value"] = 0.0  # a fast kernel with wrong results is not a result
         if world == 1 and not args.stub and args.mode == "shard" and not args.no_pipelined:
             try:
-                result["pipelined"] = pipelined_leg(V, d_sym, d_out, max(1, min(args.steps, 1000)))
+                result["pipelined"] = pipelined_leg(V, d_sym, d_out)
                 if result.get("parity") and not result["parity"]["bit_exact"]:
                     result["pipelined"]["value"] = 0.0
             except Exception as e:  # the headline line must not depend on this leg
                 result["pipelined"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and not args.stub and args.mode == "shard" and not args.no_sensitivity and args.input == "noisy":
+            try:
+                sens = input_sensitivity(V, None if args.no_cpu else _vitpkg.load_oracle(), dev, n, 1234 + rank, args.renorm_ge)
+                for rec in sens.values():
+                    rec["vs_headline"] = round(rec["value"] / result["value"] - 1.0, 4) if result["value"] else None
+                sens["what"] = ("the same batch shape on other input families, unit Mbit/s; vs_headline = relative to `value` "
+                                "(Eb/N0 = 3 dB); random_bytes = no signal at all, the speculative traceback's worst case")
+                result["input_sensitivity"] = sens
+            except Exception as e:  # the headline line must not depend on this leg
+                result["input_sensitivity"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.stub and not args.no_rs and args.mode == "shard":
             try:
                 result["second_stage"] = second_stage(V, dev)
@@ -576,15 +644,19 @@ def main(argv=None):
             _attach_cached_counters(result)
     if dist and world > 1 and args.mode == "shard" and not args.no_scatter_leg:
         # The extra leg is collective: every rank runs it.  It must never cost the run its headline line, so a
-        # watchdog ends ALL ranks cleanly (rank 0 printing the line without the leg) if it does not come back.
+        # watchdog ends ALL ranks (rank 0 printing the line with the error in it, exit code 3) if it does not come back.
         import threading
         from importlib import import_module
 
         def bail():
+            # a hung collective is a finding, not a success: the shard line is still printed (with the error in it), the
+            # exit code of every rank is non-zero, and the launcher (spawn_ranks / torchrun) passes it on
             if rank == 0:
-                result["scatter"] = {"error": "the scatter leg did not finish within %d s; shard result unaffected" % args.scatter_timeout}
+                result["scatter"] = {"error": "the scatter leg did not finish within %d s (RCCL send/recv pipeline hung or "
+                                              "far slower than predicted); the shard measurement above it completed before "
+                                              "the leg started; exit code 3" % args.scatter_timeout}
                 print(json.dumps(result), flush=True)
-            os._exit(0)
+            os._exit(3)
 
         dog = threading.Timer(args.scatter_timeout, bail)
         dog.daemon = True
@@ -687,7 +759,20 @@ def _attach_cached_counters(result):
         if k in pmc:
             r[k] = pmc[k]
     if "valu_busy" in pmc:
-        r["binding_resource"] = "VALU issue (see valu_busy); the HBM frac is reported as the north star asks"
+        r["binding_resource"] = "VALU issue (see roofline_valu); the HBM frac is reported as the north star asks"
+    if "valu_busy" in pmc and "valu_insts_per_frame_step" in pmc:
+        # the binding roofline: vector-instruction issue.  `core` = what the formulation cannot do without per frame-step:
+        # 4 v_pk_add_u16 + 2 v_pk_min_u16 + 2 v_pk_sub_u16 (decisions) + 2 v_bfi (history) + 1 v_sub (63 - M) = 11 wave
+        # instructions per trellis step of FOUR frames; issued = SQ_INSTS_VALU per wave / (4 x 774).
+        core, issued, busy = 11.0 / 4.0, float(pmc["valu_insts_per_frame_step"]), float(pmc["valu_busy"])
+        result["roofline_valu"] = {
+            "bound": "valu_issue", "unit": "wave instructions per frame-step",
+            "core": core, "issued": issued, "valu_busy": busy,
+            "useful_frac": round(core / issued * busy, 4),
+            "overhead_frac_of_issued": round(1.0 - core / issued, 4),
+            "source": r["traffic_source"],
+            "what": "useful_frac = core / issued x valu_busy: the share of the chip's vector issue slots spent on the "
+                    "add-compare-select + history core; the rest is renormalisation, lane exchange, pre-pass, traceback, set-up and idle slots"}
     ss = result.get("second_stage")
     if ss and ss.get("roofline") and pmc.get("second_stage"):
         ss["roofline"]["traffic"] = pmc["second_stage"].get("hbm_bytes_per_launch")

@@ -159,15 +159,25 @@ int vit_rs_batch_host(const uint8_t *h_p, uint8_t *h_out, int32_t *h_ret,
 int vit_dabplus_superframes_dev(const uint8_t *d_symbols_u8, uint8_t *d_work, uint8_t *d_rs_out,
                                 int32_t *d_ret, uint32_t RSDims, int64_t nsf, void *stream);
 
-/* Ingest stage for concurrent callers of deconvolve().  Off by default (window 0): every call runs on its own
- * thread's stream.  With a window > 0 the stage is ADAPTIVE: a call joins a shared launch only while at least
- * `min_callers` (default 8) deconvolve() calls are in flight in the process; below that it takes the direct
- * path, so a handful of threads never wait for each other.  Batched calls park their request; a worker thread
- * closes the batch as soon as every caller that chose to batch has arrived - `microseconds` is only the upper
- * bound of that wait - and runs ONE variable-length decode launch for all of them; each caller still blocks
- * until its own frame is done.  Both setters return the previous value. */
+/* Ingest stage for concurrent callers of deconvolve() (the reference is re-entrant and QIRX calls it from several
+ * threads, README.md:56).  `microseconds` = 0 switches it off: every call is a launch of its own on its thread's stream.
+ * With a window > 0, a call that finds at least `min_callers` deconvolve() calls in flight (itself included)
+ * claims a slot of one mapped pinned ring, copies its own symbols into it (narrowed to one byte each) and joins the
+ * open batch; the batch's first caller holds it open while `launches_in_flight` earlier batches are still on the
+ * GPU - never longer than the window - and then issues ONE launch for all members; each workgroup publishes its
+ * slot's completion word, on which the caller spins.  A lone caller finds a free launch credit and is launched at
+ * once, so nobody waits for callers that do not exist.  No worker thread, no copy by anyone but the caller itself.
+ * Environment (read when the library is loaded, for hosts that only bind the five reference exports):
+ * VITERBI_AMD_BATCH_WINDOW_US, VITERBI_AMD_BATCH_MIN_CALLERS, VITERBI_AMD_BATCH_DEPTH, VITERBI_AMD_SPIN_CPUS.
+ * Waiting: the batch's first caller polls the completion words; the others spin on their own word while the calls in
+ * flight do not exceed `cpus` (default: the process's CPU budget - affinity mask capped by a cgroup CPU quota) and
+ * otherwise sleep on a futex until the polling member wakes them (32 spinning callers in a 16-CPU container get the
+ * whole process throttled).  vit_set_batch_spin_cpus(0): always sleep.
+ * All setters return the previous value. */
 int vit_set_batch_window_us(int microseconds);
 int vit_set_batch_min_callers(int min_callers);
+int vit_set_batch_depth(int launches_in_flight);
+int vit_set_batch_spin_cpus(int cpus);
 
 /* Kernel selection (the analogue of the reference's dispatcher, setupdll.cpp:195-270):
  *   0 = auto: launches of up to 2048 frames (they cannot fill the chip) take the latency kernel - one

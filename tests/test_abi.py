@@ -89,14 +89,20 @@ def test_call_log_env(tmp_path):
 
 
 def test_ingest_stage_environment_knobs():
-    """VITERBI_AMD_BATCH_WINDOW_US / VITERBI_AMD_BATCH_MIN_CALLERS configure the ingest stage for hosts that bind only the
-    five reference exports (read once, when the library is loaded); the setters return the previous value"""
+    """VITERBI_AMD_BATCH_WINDOW_US / _MIN_CALLERS / _DEPTH and VITERBI_AMD_SPIN_CPUS configure the ingest stage for hosts
+    that bind only the five reference exports (read once, when the library is loaded); the setters return the previous
+    value.  Defaults: stage on (window 50 us), engaged from the first call in flight, three batches in flight, waiting
+    callers spin while the calls in flight fit the process's CPU budget."""
     import sys
     code = ("import sys; sys.path.insert(0, %r); import _vitpkg; V = _vitpkg.load_package();"
-            "print('RESULT', V.set_batch_window_us(0), V.set_batch_min_callers(8))" % ROOT)
-    env = dict(os.environ, VITERBI_AMD_BATCH_WINDOW_US="75", VITERBI_AMD_BATCH_MIN_CALLERS="12")
+            "print('RESULT', V.set_batch_window_us(0), V.set_batch_min_callers(8), V.set_batch_depth(5), V.set_batch_depth(99),"
+            " V.set_batch_depth(0), V.set_batch_depth(2), V.set_batch_spin_cpus(7), V.set_batch_spin_cpus(-3), V.set_batch_spin_cpus(1))" % ROOT)
+    env = dict(os.environ, VITERBI_AMD_BATCH_WINDOW_US="75", VITERBI_AMD_BATCH_MIN_CALLERS="12", VITERBI_AMD_BATCH_DEPTH="4",
+               VITERBI_AMD_SPIN_CPUS="9")
     out = subprocess.check_output([sys.executable, "-c", code], env=env, text=True)
-    assert "RESULT 75 12" in out
-    out = subprocess.check_output([sys.executable, "-c", code],
-                                  env={k: v for k, v in os.environ.items() if not k.startswith("VITERBI_AMD_BATCH")}, text=True)
-    assert "RESULT 0 8" in out
+    assert "RESULT 75 12 4 5 16 1 9 7 0" in out  # depth is clamped to 1..16, spin_cpus to >= 0
+    clean = {k: v for k, v in os.environ.items() if not k.startswith("VITERBI_AMD_BATCH") and k != "VITERBI_AMD_SPIN_CPUS"}
+    out = subprocess.check_output([sys.executable, "-c", code], env=clean, text=True)
+    ncpu = len(os.sched_getaffinity(0))
+    m = re.search(r"RESULT 50 1 4 5 16 1 (\d+) 7 0", out)
+    assert m and 1 <= int(m.group(1)) <= ncpu  # affinity mask, capped by a cgroup CPU quota

@@ -240,37 +240,86 @@ def test_deconvolve_is_thread_safe(V, O, torch_cuda):
     assert not errs
 
 
-def test_deconvolve_micro_batching(V, O, torch_cuda):
-    """ingest stage: concurrent callers share one launch; results and return codes unchanged"""
+def _run_callers(V, lens, syms, want, ncalls):
     import threading
-    lens = [768, 768, 3072, 288, 1536, 768, 9216, 8]
-    syms = [O.uniform_symbols(O.sym_len(fb), seed=fb + i).astype(np.uint32) for i, fb in enumerate(lens)]
-    want = [O.deconvolve_u32(fb, s) for fb, s in zip(lens, syms)]
     errs = []
 
     def work(i):
-        for _ in range(15):
+        for _ in range(ncalls):
             rc, got = V.deconvolve(lens[i], syms[i])
             if rc != 0 or not np.array_equal(got, want[i]):
                 errs.append(i)
 
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(lens))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    return errs
+
+
+def test_deconvolve_micro_batching(V, O, torch_cuda):
+    """ingest stage: concurrent callers share launches through the slot ring; results and return codes unchanged.
+    Mixed lengths in one batch (every workgroup its own length), every engagement threshold, one to six batches in
+    flight, waiting callers spinning (CPU budget large) and sleeping behind the batch's polling member (budget 0)."""
+    lens = [768, 768, 3072, 288, 1536, 768, 9216, 8, 770, 2, 6912, 768]
+    syms = [O.uniform_symbols(O.sym_len(fb), seed=fb + i).astype(np.uint32) | np.uint32(0x5A000000) for i, fb in enumerate(lens)]
+    want = [O.deconvolve_u32(fb, s) for fb, s in zip(lens, syms)]
     old = V.set_batch_window_us(200)
+    old_spin = V.set_batch_spin_cpus(1024)
+    old_depth = V.set_batch_depth(3)
     try:
-        # min_callers 2: every overlapping pair of calls shares a launch; 8 (the default): only while all eight
-        # threads are inside deconvolve() at once; 100: never (the adaptive stage stays on the direct path)
-        for min_callers in (2, 8, 100):
+        # min_callers 1: every call goes through the ring; 8: only while eight calls are in flight; 100: never
+        for min_callers in (1, 2, 8, 100):
             old_min = V.set_batch_min_callers(min_callers)
             try:
-                th = [threading.Thread(target=work, args=(i,)) for i in range(len(lens))]
-                [t.start() for t in th]
-                [t.join() for t in th]
+                assert not _run_callers(V, lens, syms, want, 12), min_callers
             finally:
                 V.set_batch_min_callers(old_min)
-        rc, got = V.deconvolve(770, O.uniform_symbols(O.sym_len(770), seed=1).astype(np.uint32))  # alone: never batched
-        assert rc == 0
+        V.set_batch_min_callers(1)
+        for depth, spin in ((1, 1024), (6, 1024), (1, 0), (2, 0), (3, 0), (3, 4)):
+            V.set_batch_depth(depth)
+            V.set_batch_spin_cpus(spin)
+            assert not _run_callers(V, lens, syms, want, 12), (depth, spin)
+        rc, got = V.deconvolve(770, syms[8])  # alone: a batch of one, launched at once
+        assert rc == 0 and np.array_equal(got, want[8])
+        V.set_batch_window_us(0)  # stage off: the direct path
+        rc, got = V.deconvolve(770, syms[8])
+        assert rc == 0 and np.array_equal(got, want[8])
     finally:
+        V.set_batch_min_callers(1)
+        V.set_batch_depth(old_depth)
+        V.set_batch_spin_cpus(old_spin)
         V.set_batch_window_us(old)
-    assert not errs
+
+
+def test_deconvolve_ring_many_callers_and_comparator(V, O, torch_cuda):
+    """more concurrent callers than the ring has slots (128): the surplus takes the direct path, nobody fails or waits
+    for a slot; and the `>= 150` comparator through the ring (hard-decision frames on which the two comparators differ)"""
+    n = 150
+    lens = [768] * n
+    noisy = O.noisy_frames(n, 768, seed=11)
+    syms = [noisy[i].astype(np.uint32) for i in range(n)]
+    want = list(O.decode_batch(768, noisy))
+    old = V.set_batch_window_us(100)
+    old_spin = V.set_batch_spin_cpus(0)
+    try:
+        assert not _run_callers(V, lens, syms, want, 4)
+        V.set_batch_spin_cpus(1024)
+        assert not _run_callers(V, lens[:40], syms[:40], want[:40], 6)
+        # comparator modes: 16 hard-decision frames, 3072 bits
+        rng = np.random.default_rng(77)
+        hard = [(rng.integers(0, 2, O.sym_len(3072)) * 255).astype(np.uint32) for _ in range(16)]
+        w_gt = [O.deconvolve_u32(3072, h) for h in hard]
+        w_ge = [O.deconvolve_u32(3072, h, ge=True) for h in hard]
+        assert any(not np.array_equal(a, b) for a, b in zip(w_gt, w_ge))
+        for ge, w in ((1, w_ge), (0, w_gt)):
+            old_ge = V.set_renorm_ge(ge)
+            try:
+                assert not _run_callers(V, [3072] * 16, hard, w, 3), ge
+            finally:
+                V.set_renorm_ge(old_ge)
+    finally:
+        V.set_batch_spin_cpus(old_spin)
+        V.set_batch_window_us(old)
 
 
 @pytest.mark.parametrize("framebits,n", [(768, 50), (3072, 9), (24, 5)])

@@ -11,9 +11,10 @@
 //   5. the batched host entry point.
 // No HIP, no Python: only the C ABI in include/viterbi_amd.h.
 //   g++ -O2 -std=c++17 -I include tools/vitbench.cpp -o /tmp/vitbench -ldl -lpthread
-//   /tmp/vitbench viterbi.dll_amd/libviterbi.so [frames] [loops]
+//   /tmp/vitbench viterbi.dll_amd/libviterbi.so [frames] [loops] [sweep]
 #include <dlfcn.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -76,7 +77,11 @@ int main(int argc, char** argv) {
     auto batch_host = (BATCHHOST)dlsym(h, "vit_decode_batch_host");
     auto set_window = (SETWINDOW)dlsym(h, "vit_set_batch_window_us");
     auto last_error = (LASTERR)dlsym(h, "vit_last_error");
-    if (!deconvolve || !rscheck || !initialize || !getcaps || !batch_host || !set_window) { fprintf(stderr, "missing export\n"); return 2; }
+    auto set_minc = (SETWINDOW)dlsym(h, "vit_set_batch_min_callers");
+    auto set_depth = (SETWINDOW)dlsym(h, "vit_set_batch_depth");
+    auto set_spin = (SETWINDOW)dlsym(h, "vit_set_batch_spin_cpus");
+    const bool sweep = argc > 4 && !strcmp(argv[4], "sweep");
+    if (!deconvolve || !rscheck || !initialize || !getcaps || !batch_host || !set_window || !set_minc || !set_depth || !set_spin) { fprintf(stderr, "missing export\n"); return 2; }
     initialize();
     const int caps = getcaps();
     printf("GetCPUCaps() = 0x%x (%s, %d CUs)\n", caps, (caps & VIT_CAPS_GFX950) ? "gfx950" : "no GPU", caps >> 8);
@@ -110,21 +115,58 @@ int main(int argc, char** argv) {
         const double dt = now_s() - t0;
         printf("Bitrate: %5d\tFramebits: %5u\tTime: %8.4f sec  (%.1f us/call)\n", bitrate, fb, dt, dt / loops * 1e6);
     }
-    // 3. concurrent callers
-    for (int window : {0, 50}) {
-        set_window(window);
-        for (int nt : {1, 4, 8, 16, 32}) {
+    // 3. concurrent callers, every thread with its own frame; every result compared with the single-call result
+    {
+        const int MAXT = 64;
+        const unsigned fbs[4] = {768, 768, 768, 768};
+        std::vector<std::vector<unsigned>> tsym(MAXT);
+        std::vector<std::vector<unsigned char>> want(MAXT);
+        for (int t = 0; t < MAXT; t++) {
+            const unsigned fb = fbs[t & 3];
+            tsym[t].resize(4 * (fb + 6));
+            std::vector<unsigned char> b(fb / 8);
+            make_frame(fb, gain, tsym[t].data(), b.data());
+            want[t].resize(fb / 8);
+            set_window(0);
+            deconvolve(fb, tsym[t].data(), 0, want[t].data());
+        }
+        auto run = [&](int nt, int window, int minc, int depth, const char* tag) {
+            set_window(window);
+            const int old_minc = minc > 0 ? set_minc(minc) : -1;
+            const int old_depth = depth > 0 ? set_depth(depth) : -1;
             std::vector<std::thread> th;
+            std::atomic<long> bad{0};
             const double t0 = now_s();
             for (int t = 0; t < nt; t++)
                 th.emplace_back([&, t] {
-                    std::vector<unsigned char> o(96);
-                    for (int i = 0; i < loops; i++) deconvolve(768, sym.data(), 0, o.data());
+                    const unsigned fb = fbs[t & 3];
+                    std::vector<unsigned char> o(fb / 8);
+                    for (int i = 0; i < loops; i++) {
+                        if (deconvolve(fb, tsym[t].data(), 0, o.data()) != 0 || memcmp(o.data(), want[t].data(), fb / 8) != 0) bad++;
+                    }
                 });
             for (auto& x : th) x.join();
             const double dt = now_s() - t0;
-            printf("threads %2d  batch window %2d us%s: %9.0f calls/s\n", nt, window,
-                   window ? " (adaptive: engages at >= 8 calls in flight)" : "", nt * (double)loops / dt);
+            const double cps = nt * (double)loops / dt;
+            printf("threads %2d  %s: %9.0f calls/s = %6.1f Mbit/s  (%.1f us per call per thread)%s\n", nt, tag, cps, cps * 768 / 1e6,
+                   dt / loops * 1e6, bad.load() ? "  *** WRONG RESULTS ***" : "");
+            if (bad.load()) exit(3);
+            if (old_minc > 0) set_minc(old_minc);
+            if (old_depth > 0) set_depth(old_depth);
+        };
+        for (int nt : {1, 2, 4, 8, 16, 32, 64}) run(nt, 0, 0, 0, "ingest stage off            ");
+        for (int nt : {1, 2, 4, 8, 16, 32, 64}) run(nt, 50, 0, 0, "ingest stage on (defaults)  ");
+        if (sweep) {
+            for (int spin : {-1, 0})  // -1: the library's default (CPU budget of the process), 0: waiting callers always sleep
+                for (int depth : {2, 3, 4, 6}) {
+                    const int old_spin = spin >= 0 ? set_spin(spin) : -1;
+                    for (int nt : {1, 2, 4, 8, 16, 32, 64}) {
+                        char tag[64];
+                        snprintf(tag, sizeof tag, "window 50 depth %d spin_cpus %s", depth, spin < 0 ? "default" : "0");
+                        run(nt, 50, 1, depth, tag);
+                    }
+                    if (old_spin >= 0) set_spin(old_spin);
+                }
         }
     }
     set_window(0);

@@ -20,7 +20,7 @@ TAIL = 6
 
 EXPORTS = [
     "deconvolve", "initialize", "RScheckSuperframe", "RSCheckSuperframe", "GetCPUCaps", "WakeUpYMM",
-    "vit_last_error", "vit_device_count", "vit_set_kernel", "vit_set_renorm_ge", "vit_set_batch_window_us", "vit_set_batch_min_callers",
+    "vit_last_error", "vit_device_count", "vit_set_kernel", "vit_set_renorm_ge", "vit_set_batch_window_us", "vit_set_batch_min_callers", "vit_set_batch_depth", "vit_set_batch_spin_cpus",
     "vit_decode_batch_dev",
     "vit_decode_batch_dev_u32", "vit_decode_varlen_dev", "vit_decode_varlen_dev_checked", "vit_pack_symbols_dev", "vit_sort_descs",
     "vit_decode_batch_host", "vit_rs_batch_dev", "vit_rs_batch_host", "vit_dabplus_superframes_dev",
@@ -73,6 +73,8 @@ def lib():
         L.vit_set_renorm_ge.argtypes = [C.c_int]
         L.vit_set_batch_window_us.argtypes = [C.c_int]
         L.vit_set_batch_min_callers.argtypes = [C.c_int]
+        L.vit_set_batch_depth.argtypes = [C.c_int]
+        L.vit_set_batch_spin_cpus.argtypes = [C.c_int]
         L.vit_decode_batch_dev.argtypes = [vp, vp, C.c_uint32, C.c_int64, vp]
         L.vit_decode_batch_dev_u32.argtypes = [vp, vp, C.c_uint32, C.c_int64, vp]
         L.vit_decode_varlen_dev.argtypes = [vp, vp, vp, C.c_int64, C.c_uint32, vp]
@@ -135,6 +137,14 @@ def set_batch_window_us(us):
 
 def set_batch_min_callers(n):
     return int(lib().vit_set_batch_min_callers(int(n)))
+
+
+def set_batch_depth(n):
+    return int(lib().vit_set_batch_depth(int(n)))
+
+
+def set_batch_spin_cpus(n):
+    return int(lib().vit_set_batch_spin_cpus(int(n)))
 
 
 def deconvolve(framebits, symbols, unused=0, decoded=None):

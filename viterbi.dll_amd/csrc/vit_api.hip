@@ -8,12 +8,17 @@
 // Reference boundary being replaced: viterbi.def:4-8, deconvolve.cpp:551-554,
 // rschecksf.cpp:65-93, dllmain.cpp:156-160, setupdll.cpp:195-270 (dispatcher),
 // exc_handler.cpp:150-249 (fault -> save mode).
+#include <emmintrin.h>
+#include <linux/futex.h>
 #include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
+#include <climits>
 
 #include <algorithm>
 #include <atomic>
 #include <chrono>
-#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -287,31 +292,160 @@ int launch_decode_u32(DecodeMode mode, const uint32_t* d_sym32, uint8_t* d_scrat
     return launch_decode(mode, d_scratch8, d_out, d_desc, framebits, max_framebits, nframes, s);
 }
 
-// ---- ingest stage: micro-batching of concurrent deconvolve() callers -------------
-// Off by default (window 0): every call then runs on its own thread's stream.  With a window of
-// w microseconds, callers park their request in a queue; one worker thread collects what arrives
-// within w us of the first request (or up to MAX_BATCH), stages all symbol buffers in pinned
-// memory, and runs ONE u32->u8 pack + ONE variable-length decode for the batch.
-struct BatchReq {
-    uint32_t framebits;
-    const unsigned int* symbols;
-    unsigned char* out;
-    int rc;
-    bool done;
+// ---- ingest stage: concurrent deconvolve() callers share launches ------------------
+// The reference is re-entrant and QIRX calls it from several threads (README.md:56).  One call is one 774-step
+// dependent chain on one wavefront (~35 us) however empty the GPU is, and a process's streams share a handful of
+// hardware queues, so separate launches of concurrent callers queue up behind each other.  The stage:
+//
+//   * ONE mapped pinned buffer cut into slots.  A caller claims a slot, copies its OWN symbols into it - narrowing
+//     the reference ABI's u32 to the device format's one byte per symbol on the way (low byte, deconvolve.cpp:158-165:
+//     a quarter of the PCIe traffic) - and spins on the slot's completion word.  Callers copy in parallel; there is
+//     no worker thread, no H2D/D2H copy, no descriptor table in memory, no condition variable.
+//   * The first caller to arrive while no batch is open becomes that batch's LEADER: it holds the batch open until
+//     one of `depth` launch credits is free (i.e. while `depth` earlier batches are still on the GPU, at most
+//     `window` microseconds), closes it, and issues ONE bounded launch of the latency kernel with grid = members
+//     (vit_lat_ring_kernel: the slot table travels by value in the kernel arguments).  Batches therefore form
+//     exactly when launches would otherwise queue: a lone caller finds a credit and launches at once.
+//   * Every workgroup publishes the batch's sequence number in its slot's completion word after its last output
+//     byte (system-scope release); the caller copies its bytes out and frees the slot.
+struct SpinLock {  // test-and-test-and-set; held for a few dozen instructions (join / close a batch)
+    std::atomic<int> f{0};
+    void lock() {
+        for (unsigned n = 1;; n++) {
+            if (f.load(std::memory_order_relaxed) == 0 && f.exchange(1, std::memory_order_acquire) == 0) return;
+            __builtin_ia32_pause();
+            if ((n & 1023u) == 0) sched_yield();  // the holder may have lost its core
+        }
+    }
+    void unlock() { f.store(0, std::memory_order_release); }
 };
-struct Batcher {
-    std::mutex mu;
-    std::condition_variable cv_work, cv_done;
-    std::vector<BatchReq*> q;
-    std::atomic<int> window_us{0};
-    std::atomic<int> min_callers{8};  // batching engages only while at least this many deconvolve() calls are in flight
-    std::atomic<int> inflight{0};     // deconvolve() calls currently executing (any path)
-    int committed = 0;                // callers that chose the batch path and are not in a batch yet (under mu)
-    bool started = false;
-    static constexpr size_t MAX_BATCH = 256;
-    Batcher() {
+
+// u32 -> u8 (low byte) while copying a caller's symbols into pinned memory; n is a multiple of 8
+void narrow_symbols(const unsigned int* src, uint8_t* dst, size_t n) {
+    size_t i = 0;
+    const __m128i lo = _mm_set1_epi32(0xFF);
+    for (; i + 16 <= n; i += 16) {
+        const __m128i a = _mm_and_si128(_mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i)), lo);
+        const __m128i b = _mm_and_si128(_mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 4)), lo);
+        const __m128i c = _mm_and_si128(_mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 8)), lo);
+        const __m128i d = _mm_and_si128(_mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 12)), lo);
+        // values are 0..255: the signed/unsigned saturating packs are exact
+        _mm_storeu_si128(reinterpret_cast<__m128i*>(dst + i), _mm_packus_epi16(_mm_packs_epi32(a, b), _mm_packs_epi32(c, d)));
+    }
+    for (; i < n; i++) dst[i] = (uint8_t)src[i];
+}
+
+constexpr uint32_t RING_SLOTS = VIT_RING_MAXB;   // concurrent callers the ring serves; further ones take the direct path
+constexpr uint32_t RING_SYM_CAP = 36992;         // >= 4 * (9216 + 6) one-byte symbols
+constexpr uint32_t RING_OUT_OFF = RING_SYM_CAP;  // 1152 output bytes
+constexpr uint32_t RING_FLAG_OFF = RING_OUT_OFF + 1152;  // completion word, on a cache line of its own
+constexpr uint32_t RING_STRIDE = 38400;
+static_assert(RING_SYM_CAP >= 4 * (VIT_MAX_FRAMEBITS + VIT_TAIL) && RING_FLAG_OFF % 64 == 0 && RING_FLAG_OFF + 64 <= RING_STRIDE &&
+              RING_STRIDE % 128 == 0, "ring slot layout");
+enum { RING_OK = 0, RING_FAILED = 1, RING_DECLINED = 2 };
+constexpr int RING_MAX_DEPTH = 16;
+
+long futex_wait(std::atomic<uint32_t>* a, uint32_t expected, long timeout_ns) {
+    timespec ts{0, timeout_ns};
+    return syscall(SYS_futex, reinterpret_cast<uint32_t*>(a), FUTEX_WAIT_PRIVATE, expected, &ts, nullptr, 0);
+}
+void futex_wake_all(std::atomic<uint32_t>* a) {
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(a), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+}
+// CPUs this process may keep busy: the affinity mask, capped by a cgroup CPU quota (a container that may use 16 CPUs'
+// worth of time on a 256-CPU host is THROTTLED when 32 threads spin).  Waiting callers spin only while the calls in
+// flight fit this budget; beyond it all but one per batch sleep on a futex.
+int detect_cpu_budget() {
+    cpu_set_t set;
+    int n = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : 1;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+        char q[32] = "";
+        long period = 0;
+        if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const long cpus = (atol(q) + period - 1) / period;
+            if (cpus > 0 && cpus < n) n = (int)cpus;
+        }
+        fclose(f);
+    } else {
+        long quota = -1, period = 0;  // cgroup v1
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%ld", &quota) != 1) quota = -1; fclose(g); }
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%ld", &period) != 1) period = 0; fclose(g); }
+        if (quota > 0 && period > 0 && (quota + period - 1) / period < n) n = (int)((quota + period - 1) / period);
+    }
+    return n < 1 ? 1 : n;
+}
+
+// VITERBI_AMD_RING_STATS=1: where a call's time goes, printed to stderr (and reset) by every vit_set_batch_window_us() call
+struct RingStats {
+    const bool on = getenv("VITERBI_AMD_RING_STATS") != nullptr;
+    std::atomic<uint64_t> calls{0}, batches{0}, declined{0}, ns_call{0}, ns_copy{0}, ns_token{0}, ns_members{0}, ns_launch{0},
+        ns_leader_wait{0}, ns_follower_wait{0}, ns_wake_delay{0}, wakes{0}, slept{0}, takeovers{0}, no_token{0};
+    static uint64_t now() {
+        return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
+    void print_and_reset() {
+        const uint64_t c = calls.exchange(0), b = batches.exchange(0);
+        if (c && b)
+            fprintf(stderr,
+                    "[ring] calls %llu batches %llu (%.1f per batch) declined %llu | per call: total %.1f us copy %.1f | per batch: token wait %.1f "
+                    "members' copies %.1f launch call %.1f leader wait %.1f | followers: wait %.1f us, slept %llu, wake delay %.1f us (%llu), "
+                    "poller take-overs %llu, launches without token %llu\n",
+                    (unsigned long long)c, (unsigned long long)b, (double)c / b, (unsigned long long)declined.load(), ns_call.load() / 1e3 / c,
+                    ns_copy.load() / 1e3 / c, ns_token.load() / 1e3 / b, ns_members.load() / 1e3 / b, ns_launch.load() / 1e3 / b,
+                    ns_leader_wait.load() / 1e3 / b, c > b ? ns_follower_wait.load() / 1e3 / (c - b) : 0.0, (unsigned long long)slept.load(),
+                    wakes.load() ? ns_wake_delay.load() / 1e3 / wakes.load() : 0.0, (unsigned long long)wakes.load(),
+                    (unsigned long long)takeovers.load(), (unsigned long long)no_token.load());
+        for (auto* a : {&declined, &ns_call, &ns_copy, &ns_token, &ns_members, &ns_launch, &ns_leader_wait, &ns_follower_wait, &ns_wake_delay,
+                        &wakes, &slept, &takeovers, &no_token})
+            a->store(0);
+    }
+};
+RingStats g_rstat;
+
+struct RingBatch {
+    VitRingTable tbl;                  // members (what the kernel receives by value)
+    uint32_t maxfb = 0;
+    bool ge = false;
+    int token = -1;                    // launch token (= index of the ring stream) the leader holds, -1: none
+    hipStream_t stream = nullptr;      // the stream the batch was launched on
+    std::atomic<uint32_t> copied{0};   // members whose symbols are in their slot
+    std::atomic<int> state{0};         // 0 not launched yet, 1 launched, 2 failed before the launch, 3 failed after it
+    std::atomic<uint32_t> refs{0};     // members that have not left yet
+    // waiting: ONE member at a time (the leader first) is the batch's poller: it spins on the completion words and
+    // wakes the members that sleep; the others spin on their own word while CPUs are to spare, or sleep
+    std::atomic<int> poller{0};                        // 1 while a member polls for the others
+    std::atomic<uint32_t> wake[VIT_RING_MAXB];         // per member futex word: 0 = must wait, WAKE_DONE, WAKE_POLL
+    std::atomic<uint8_t> asleep[VIT_RING_MAXB];        // member sleeps (or is about to) on its futex word
+    std::atomic<uint8_t> gone[VIT_RING_MAXB];          // member has seen its own completion (its slot may be reused)
+    std::atomic<uint64_t> t_seen[VIT_RING_MAXB];       // statistics only: when the poller saw the member's completion
+};
+enum : uint32_t { WAKE_DONE = 1, WAKE_POLL = 2 };
+struct Ring {
+    SpinLock mu;                       // joining and closing the open batch; everything else is lock-free
+    std::once_flag once;
+    int init_rc = VIT_ERR_HIP;
+    uint8_t* h_base = nullptr;
+    uint8_t* d_base = nullptr;
+    // free slots / batch records: bit masks; claimed under `mu` (one claimer at a time), released with one atomic OR
+    std::atomic<uint64_t> slot_free[2] = {};
+    std::atomic<uint64_t> batch_free[2] = {};
+    RingBatch batches[RING_SLOTS];     // every live batch has a member holding a slot: never more than RING_SLOTS
+    RingBatch* open = nullptr;         // the batch a new caller joins (under mu)
+    uint32_t seq = 0;
+    // launch tokens: token i = the right to have one batch in flight on streams[i].  Batches in flight therefore never
+    // share a stream (streams of arbitrary caller threads would: a process's streams are multiplexed onto a few
+    // hardware queues, and two batches on one queue run one after the other).
+    hipStream_t streams[RING_MAX_DEPTH] = {};
+    std::atomic<uint32_t> token_free{(1u << RING_MAX_DEPTH) - 1u};
+    std::atomic<int> depth{4};         // batches in flight
+    std::atomic<int> window_us{50};    // 0 = stage off
+    std::atomic<int> min_callers{1};   // engage only while at least this many deconvolve() calls are in flight
+    std::atomic<int> inflight{0};      // deconvolve() calls currently executing (any path)
+    std::atomic<int> spin_cpus{0};     // waiting callers spin while the calls in flight do not exceed this
+
+    Ring() {
         // a host that only binds the five reference exports configures the stage through the environment
-        // (the analogue of the reference's viterbi.txt): window in microseconds (0 = off) and the engagement threshold
+        // (the analogue of the reference's viterbi.txt)
         if (const char* e = getenv("VITERBI_AMD_BATCH_WINDOW_US")) {
             const int w = atoi(e);
             window_us.store(w < 0 ? 0 : w > 100000 ? 100000 : w);
@@ -320,110 +454,313 @@ struct Batcher {
             const int n = atoi(e);
             min_callers.store(n < 1 ? 1 : n);
         }
+        if (const char* e = getenv("VITERBI_AMD_BATCH_DEPTH")) set_depth(atoi(e));
+        if (const char* e = getenv("VITERBI_AMD_SPIN_CPUS")) spin_cpus.store(atoi(e) < 0 ? 0 : atoi(e));
     }
-    std::vector<vit_frame_desc> h_desc;
-    void* d_desc = nullptr; size_t ddesc_cap = 0;
-
-    int process(std::vector<BatchReq*>& b) {
-        VitDeviceGuard guard(g_device);
-        int rc = ctx_prepare(g_device);  // the worker thread has its own stream and buffers
-        if (rc != VIT_OK) return rc;
-        size_t nsym = 0, nout = 0;
-        uint32_t maxfb = 0;
-        h_desc.resize(b.size());
-        for (size_t i = 0; i < b.size(); i++) {
-            const uint32_t fb = b[i]->framebits;
-            h_desc[i].sym_offset = nsym;  // one byte per symbol after narrowing; multiple of 4
-            h_desc[i].out_offset = nout;
-            h_desc[i].framebits = fb;
-            h_desc[i].reserved = 0;
-            nsym += 4u * ((size_t)fb + VIT_TAIL);
-            nout += (fb + 7u) >> 3;
-            maxfb = fb > maxfb ? fb : maxfb;
-        }
-        const size_t desc_bytes = b.size() * sizeof(vit_frame_desc);
-        const size_t out_pad = (nout + 15u) & ~(size_t)15u;
-        if ((rc = grow_pin(nsym * 4 + out_pad + desc_bytes + 64)) != VIT_OK) return rc;
-        if ((rc = grow_dev(&t_ctx.d_in, &t_ctx.din_cap, nsym * 4)) != VIT_OK) return rc;
-        if ((rc = grow_dev(&t_ctx.d_sym8, &t_ctx.d8_cap, nsym)) != VIT_OK) return rc;
-        if ((rc = grow_dev(&t_ctx.d_out, &t_ctx.dout_cap, nout)) != VIT_OK) return rc;
-        if ((rc = grow_dev(&d_desc, &ddesc_cap, desc_bytes)) != VIT_OK) return rc;
-        unsigned char* pin = (unsigned char*)t_ctx.h_pin;
-        unsigned char* h_out = pin + nsym * 4;
-        unsigned char* h_d = h_out + out_pad;
-        size_t off = 0;
-        for (BatchReq* r : b) {
-            const size_t n = 4u * ((size_t)r->framebits + VIT_TAIL);
-            memcpy(pin + off * 4, r->symbols, n * 4);
-            off += n;
-        }
-        memcpy(h_d, h_desc.data(), desc_bytes);
-        hipStream_t s = t_ctx.stream;
-        HIPCHK(hipMemcpyAsync(t_ctx.d_in, pin, nsym * 4, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(d_desc, h_d, desc_bytes, hipMemcpyHostToDevice, s));
-        // sym_offset counts symbols: the same table addresses the u32 buffer and its narrowed copy
-        rc = launch_decode_u32(decode_mode(), (const uint32_t*)t_ctx.d_in, (uint8_t*)t_ctx.d_sym8, (uint8_t*)t_ctx.d_out,
-                               (const vit_frame_desc*)d_desc, 0, maxfb, (int64_t)b.size(), (int64_t)nsym, s);
-        if (rc != VIT_OK) return rc;
-        HIPCHK(hipMemcpyAsync(h_out, t_ctx.d_out, nout, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        for (size_t i = 0; i < b.size(); i++)
-            memcpy(b[i]->out, h_out + h_desc[i].out_offset, (b[i]->framebits + 7u) >> 3);
-        return VIT_OK;
-    }
-
-    void run() {
-        std::vector<BatchReq*> batch;
+    int set_depth(int n) { return depth.exchange(n < 1 ? 1 : n > RING_MAX_DEPTH ? RING_MAX_DEPTH : n); }
+    int take_token() {  // -1: `depth` batches are in flight
+        uint32_t f = token_free.load(std::memory_order_relaxed);
         for (;;) {
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv_work.wait(lk, [&] { return !q.empty(); });
-                // The window is an upper bound, not a delay: the batch closes as soon as every caller that has
-                // chosen the batch path has arrived (`committed` counts them from their decision on).
-                const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us.load());
-                while (q.size() < MAX_BATCH && (int)q.size() < committed &&
-                       cv_work.wait_until(lk, deadline) != std::cv_status::timeout) {}
-                committed -= (int)q.size();
-                batch.swap(q);
-            }
-            const int rc = process(batch);
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                for (BatchReq* r : batch) { r->rc = rc; r->done = true; }
-            }
-            cv_done.notify_all();
-            batch.clear();
+            if (RING_MAX_DEPTH - __builtin_popcount(f) >= depth.load(std::memory_order_relaxed) || f == 0) return -1;
+            const int t = __builtin_ctz(f);
+            if (token_free.compare_exchange_weak(f, f & ~(1u << t), std::memory_order_acquire)) return t;
         }
+    }
+    static int claim_bit(std::atomic<uint64_t> (&m)[2]) {  // under mu; -1: none
+        for (int w = 0; w < 2; w++) {
+            const uint64_t v = m[w].load(std::memory_order_acquire);
+            if (v) {
+                const int bit = __builtin_ctzll(v);
+                m[w].fetch_and(~(1ull << bit), std::memory_order_acquire);
+                return w * 64 + bit;
+            }
+        }
+        return -1;
+    }
+    static void free_bit(std::atomic<uint64_t> (&m)[2], uint32_t i) { m[i >> 6].fetch_or(1ull << (i & 63u), std::memory_order_release); }
+    void allocate() {
+        VitDeviceGuard guard(g_device);
+        void* h = nullptr;
+        void* d = nullptr;
+        if (hipHostMalloc(&h, (size_t)RING_SLOTS * RING_STRIDE, hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (h) (void)hipHostFree(h);
+            return;
+        }
+        for (int i = 0; i < RING_MAX_DEPTH; i++)
+            if (hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking) != hipSuccess) {
+                (void)hipGetLastError();
+                return;
+            }
+        h_base = (uint8_t*)h;
+        d_base = (uint8_t*)d;
+        for (uint32_t i = 0; i < RING_SLOTS; i++) {
+            batches[i].tbl.stride = RING_STRIDE;
+            batches[i].tbl.out_off = RING_OUT_OFF;
+            batches[i].tbl.flag_off = RING_FLAG_OFF;
+        }
+        static_assert(RING_SLOTS == 128, "two 64-bit masks");
+        slot_free[0] = slot_free[1] = batch_free[0] = batch_free[1] = ~0ull;
+        init_rc = VIT_OK;
+    }
+    bool engaged(const DecodeMode& mode) {
+        if (window_us.load(std::memory_order_relaxed) <= 0) return false;
+        if (mode.kernel != K_AUTO && mode.kernel != K_LATENCY) return false;  // a forced kernel keeps the direct path
+        return inflight.load(std::memory_order_relaxed) >= min_callers.load(std::memory_order_relaxed);
+    }
+    uint32_t* flag_of(uint32_t slot) { return reinterpret_cast<uint32_t*>(h_base + (size_t)slot * RING_STRIDE + RING_FLAG_OFF); }
+    int call(const DecodeMode& mode, uint32_t framebits, const unsigned int* symbols, unsigned char* out);
+    int wait_done(RingBatch* b, uint32_t idx, uint32_t* flag, uint32_t my_seq, bool leader);
+};
+Ring* g_ring = new Ring();  // intentionally never destroyed (calls may come from other threads during exit)
+
+// Waits until this member's completion word carries the batch's sequence number.  Returns RING_OK / RING_FAILED.
+int Ring::wait_done(RingBatch* b, uint32_t idx, uint32_t* flag, uint32_t my_seq, bool leader) {
+    auto mine_done = [&] { return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == my_seq; };
+    const auto t0 = std::chrono::steady_clock::now();
+    bool synced = false;
+    // Every few hundred iterations: has the launch failed, is it overdue?  (true = give up)
+    auto overdue = [&]() -> bool {
+        if (b->state.load(std::memory_order_acquire) >= 2) return !mine_done();
+        const auto waited = std::chrono::steady_clock::now() - t0;
+        if (leader && !synced && waited > std::chrono::milliseconds(20)) {
+            // not what a healthy launch does: fall back to the stream's own completion, once
+            const hipError_t e = b->stream ? hipStreamSynchronize(b->stream) : hipErrorUnknown;
+            synced = true;
+            if (e != hipSuccess || !mine_done()) {
+                set_err("deconvolve: the batch launch did not complete (%s)", hipGetErrorString(e));
+                b->state.store(3, std::memory_order_release);
+                return true;
+            }
+        } else if (waited > std::chrono::seconds(10)) {
+            set_err("deconvolve: no completion from the batch launch");
+            b->state.store(3, std::memory_order_release);
+            return true;
+        }
+        return false;
+    };
+    auto wake_member = [&](uint32_t i, uint32_t what) {
+        b->wake[i].store(what, std::memory_order_seq_cst);
+        if (b->asleep[i].load(std::memory_order_seq_cst))
+            (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(&b->wake[i]), FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0);
+    };
+    // This member leaves (or failed): if others still wait asleep, ONE of them must poll from here on.
+    auto pass_on = [&] {
+        const uint32_t n = b->tbl.n;
+        for (uint32_t i = 0; i < n; i++) {
+            if (i == idx || b->gone[i].load(std::memory_order_relaxed)) continue;
+            if (__atomic_load_n(flag_of(b->tbl.slot[i]), __ATOMIC_RELAXED) == my_seq) { wake_member(i, WAKE_DONE); continue; }
+            if (b->asleep[i].load(std::memory_order_seq_cst)) { wake_member(i, WAKE_POLL); return; }
+        }
+    };
+    bool polling = leader;  // the leader has taken the poller's role before the launch
+    bool seen[VIT_RING_MAXB];
+    for (;;) {
+        if (polling) {
+            // ---- poller: watch every member's word, wake the sleeper whose frame is done ----
+            const uint32_t n = b->tbl.n;  // final: the batch was closed before its launch, and only a launched batch is polled
+            for (uint32_t i = 0; i < n; i++) seen[i] = i == idx;
+            uint32_t left = n - 1;
+            for (unsigned it = 1;; it++) {
+                for (uint32_t i = 0; i < n && left; i++) {
+                    if (seen[i]) continue;
+                    if (b->gone[i].load(std::memory_order_relaxed)) { seen[i] = true; left--; continue; }
+                    if (__atomic_load_n(flag_of(b->tbl.slot[i]), __ATOMIC_RELAXED) == my_seq) {
+                        seen[i] = true;
+                        left--;
+                        if (g_rstat.on) b->t_seen[i].store(RingStats::now(), std::memory_order_relaxed);
+                        wake_member(i, WAKE_DONE);
+                    }
+                }
+                const bool failed = (it & 255u) == 0 && overdue();
+                if (mine_done() || failed) {
+                    // hand the role to a member that still waits asleep (a spinning one needs nobody)
+                    b->poller.store(0, std::memory_order_seq_cst);
+                    if (failed) {
+                        for (uint32_t i = 0; i < n; i++)
+                            if (!seen[i]) wake_member(i, WAKE_DONE);  // they find the batch's state themselves
+                    } else if (left) {
+                        pass_on();
+                    }
+                    return failed ? RING_FAILED : RING_OK;
+                }
+                __builtin_ia32_pause();
+            }
+        }
+        // ---- not the poller: spin on the own word while CPUs are to spare, else sleep until the poller wakes us ----
+        if (inflight.load(std::memory_order_relaxed) <= spin_cpus.load(std::memory_order_relaxed)) {
+            for (unsigned it = 1; !mine_done(); it++) {
+                __builtin_ia32_pause();
+                if ((it & 255u) == 0) {
+                    if (overdue()) return RING_FAILED;
+                    if (inflight.load(std::memory_order_relaxed) > spin_cpus.load(std::memory_order_relaxed)) break;  // crowded now
+                }
+            }
+            if (mine_done()) return RING_OK;
+        }
+        b->asleep[idx].store(1, std::memory_order_seq_cst);
+        const uint32_t w = b->wake[idx].load(std::memory_order_seq_cst);
+        if (mine_done()) {
+            if (w == WAKE_POLL) pass_on();  // asked to poll, but already done
+            return RING_OK;
+        }
+        int expect = 0;
+        if (w == WAKE_POLL ||
+            (b->state.load(std::memory_order_acquire) == 1 && b->poller.load(std::memory_order_seq_cst) == 0 &&
+             b->poller.compare_exchange_strong(expect, 1, std::memory_order_seq_cst))) {
+            if (w == WAKE_POLL) b->poller.store(1, std::memory_order_seq_cst);
+            b->wake[idx].store(0, std::memory_order_relaxed);
+            b->asleep[idx].store(0, std::memory_order_seq_cst);
+            polling = true;  // the poller has left with its own frame done: this member polls from here on
+            if (g_rstat.on) g_rstat.takeovers++;
+            continue;
+        }
+        if (w == 0) {
+            if (g_rstat.on) g_rstat.slept++;
+            futex_wait(&b->wake[idx], 0, 2000000);  // 2 ms: a missed wake-up costs time, never the result
+        }
+        if (mine_done()) {
+            if (g_rstat.on) {
+                const uint64_t ts = b->t_seen[idx].load(std::memory_order_relaxed);
+                if (ts) { g_rstat.ns_wake_delay += RingStats::now() - ts; g_rstat.wakes++; }
+            }
+            if (b->wake[idx].load(std::memory_order_seq_cst) == WAKE_POLL) pass_on();
+            return RING_OK;
+        }
+        if (overdue()) return RING_FAILED;
+    }
+}
+
+int Ring::call(const DecodeMode& mode, uint32_t framebits, const unsigned int* symbols, unsigned char* out) {
+    std::call_once(once, [this] {
+        if (spin_cpus.load() == 0 && !getenv("VITERBI_AMD_SPIN_CPUS")) spin_cpus.store(detect_cpu_budget() / 4);
+        allocate();
+    });
+    if (init_rc != VIT_OK) return RING_DECLINED;
+    const bool st = g_rstat.on;
+    const uint64_t t_in = st ? RingStats::now() : 0;
+    // ---- join the open batch, or open one ----
+    mu.lock();
+    RingBatch* b = open;
+    const int slot_i = (b && b->ge != mode.ge) ? -1 : claim_bit(slot_free);
+    if (slot_i < 0) {
+        mu.unlock();
+        if (st) g_rstat.declined++;
+        return RING_DECLINED;
+    }
+    const uint32_t slot = (uint32_t)slot_i;
+    const bool leader = b == nullptr;
+    if (leader) {
+        b = &batches[claim_bit(batch_free)];  // never fails: a live batch holds a slot, and there are as many records as slots
+        b->tbl.n = 0;
+        if (++seq == 0) ++seq;
+        b->tbl.seq = seq;
+        b->maxfb = 0;
+        b->ge = mode.ge;
+        b->token = -1;
+        b->stream = nullptr;
+        b->copied.store(0, std::memory_order_relaxed);
+        b->state.store(0, std::memory_order_relaxed);
+        b->refs.store(0, std::memory_order_relaxed);
+        b->poller.store(1, std::memory_order_relaxed);  // the leader
+        open = b;
+    }
+    const uint32_t idx = b->tbl.n++;
+    b->tbl.slot[idx] = (uint16_t)slot;
+    b->tbl.fb[idx] = (uint16_t)framebits;
+    b->gone[idx].store(0, std::memory_order_relaxed);
+    b->asleep[idx].store(0, std::memory_order_relaxed);
+    b->wake[idx].store(0, std::memory_order_relaxed);
+    b->t_seen[idx].store(0, std::memory_order_relaxed);
+    if (framebits > b->maxfb) b->maxfb = framebits;
+    b->refs.fetch_add(1, std::memory_order_relaxed);
+    if (b->tbl.n == VIT_RING_MAXB) open = nullptr;
+    const uint32_t my_seq = b->tbl.seq;
+    mu.unlock();
+
+    // ---- the caller's own copy, in parallel with everybody else's ----
+    uint8_t* hs = h_base + (size_t)slot * RING_STRIDE;
+    uint32_t* flag = flag_of(slot);
+    __atomic_store_n(flag, 0u, __ATOMIC_RELAXED);
+    narrow_symbols(symbols, hs, 4u * ((size_t)framebits + VIT_TAIL));
+    b->copied.fetch_add(1, std::memory_order_release);
+    const uint64_t t_copied = st ? RingStats::now() : 0;
+    uint64_t t_wait0 = t_copied;
+
+    if (leader) {
+        // hold the batch open while `depth` launches are in flight (bounded by the window), then close it
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us.load(std::memory_order_relaxed));
+        int token = -1;
+        for (unsigned spins = 1; (token = take_token()) < 0; spins++) {
+            __builtin_ia32_pause();
+            if ((spins & 31u) == 0 && std::chrono::steady_clock::now() > deadline) break;
+        }
+        const uint64_t t_tok = st ? RingStats::now() : 0;
+        mu.lock();
+        if (open == b) open = nullptr;
+        const uint32_t n = b->tbl.n;
+        mu.unlock();
+        for (unsigned spins = 1; b->copied.load(std::memory_order_acquire) < n; spins++) {  // members still copying
+            __builtin_ia32_pause();
+            if ((spins & 1023u) == 0) sched_yield();
+        }
+        const uint64_t t_mem = st ? RingStats::now() : 0;
+        hipError_t e = hipErrorUnknown;
+        {
+            VitDeviceGuard guard(g_device);
+            hipStream_t s = nullptr;
+            if (token >= 0) s = streams[token];
+            else if (ctx_prepare(g_device) == VIT_OK) s = t_ctx.stream;  // the window ran out: one launch beyond `depth`, on this thread's stream
+            if (s) {
+                b->token = token;
+                b->stream = s;
+                e = vit_launch_lat_ring(d_base, b->tbl, b->maxfb, s, b->ge);
+                if (e != hipSuccess) set_err("deconvolve: batch launch: %s", hipGetErrorString(e));
+            }
+        }
+        b->state.store(e == hipSuccess ? 1 : 2, std::memory_order_release);
+        if (st) {
+            t_wait0 = RingStats::now();
+            g_rstat.batches++;
+            g_rstat.ns_token += t_tok - t_copied;
+            g_rstat.ns_members += t_mem - t_tok;
+            g_rstat.ns_launch += t_wait0 - t_mem;
+            if (token < 0) g_rstat.no_token++;
+        }
+        if (e != hipSuccess)  // nobody will ever be woken by a completion word
+            for (uint32_t i = 0; i < n; i++)
+                if (i != idx) {
+                    b->wake[i].store(WAKE_DONE, std::memory_order_seq_cst);
+                    (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(&b->wake[i]), FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0);
+                }
     }
 
-    // A caller takes the batch path only while enough calls are in flight to make a shared launch pay: with a
-    // handful of threads every call keeps its own stream and never waits for anybody (profiles/r02_vitbench.txt).
-    bool should_batch() {
-        if (window_us.load(std::memory_order_relaxed) <= 0) return false;
-        if (inflight.load(std::memory_order_relaxed) < min_callers.load(std::memory_order_relaxed)) return false;
-        std::lock_guard<std::mutex> lk(mu);
-        committed++;
-        return true;
+    const int rc = wait_done(b, idx, flag, my_seq, leader);
+    if (rc == RING_OK) memcpy(out, hs + RING_OUT_OFF, (framebits + 7u) >> 3);
+    else if (!leader) set_err("deconvolve: the shared launch failed");
+    if (st) {
+        const uint64_t t_out = RingStats::now();
+        g_rstat.calls++;
+        g_rstat.ns_call += t_out - t_in;
+        g_rstat.ns_copy += t_copied - t_in;
+        (leader ? g_rstat.ns_leader_wait : g_rstat.ns_follower_wait) += t_out - t_wait0;
     }
-    int submit(uint32_t framebits, const unsigned int* symbols, unsigned char* out) {  // after should_batch() == true
-        BatchReq r{framebits, symbols, out, VIT_ERR_HIP, false};
-        std::unique_lock<std::mutex> lk(mu);
-        if (!started) {
-            started = true;
-            std::thread([this] { run(); }).detach();  // lives until the process ends
-        }
-        q.push_back(&r);
-        cv_work.notify_one();
-        cv_done.wait(lk, [&] { return r.done; });
-        return r.rc;
-    }
-};
+    // ---- leave: no lock ----
+    // the leader's frame is done: its launch has at least started to retire, the next batch may go
+    if (leader && b->token >= 0) token_free.fetch_or(1u << b->token, std::memory_order_release);
+    const int final_state = b->state.load(std::memory_order_acquire);
+    b->gone[idx].store(1, std::memory_order_release);
+    // a slot whose kernel may still be running (failure after the launch) is never handed out again
+    if (rc == RING_OK || final_state == 2) free_bit(slot_free, slot);
+    if (b->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) free_bit(batch_free, (uint32_t)(b - batches));
+    return rc;
+}
 struct InflightGuard {
     std::atomic<int>& n;
     explicit InflightGuard(std::atomic<int>& c) : n(c) { n.fetch_add(1, std::memory_order_relaxed); }
     ~InflightGuard() { n.fetch_sub(1, std::memory_order_relaxed); }
 };
-Batcher* g_batcher = new Batcher();  // intentionally never destroyed (worker may outlive static dtors)
 
 }  // namespace
 
@@ -473,13 +810,18 @@ int vit_device_count(void) {
 int vit_set_batch_window_us(int microseconds) {
     if (microseconds < 0) microseconds = 0;
     if (microseconds > 100000) microseconds = 100000;
-    return g_batcher->window_us.exchange(microseconds);
+    if (g_rstat.on) g_rstat.print_and_reset();
+    return g_ring->window_us.exchange(microseconds);
 }
 
 int vit_set_batch_min_callers(int n) {
     if (n < 1) n = 1;
-    return g_batcher->min_callers.exchange(n);
+    return g_ring->min_callers.exchange(n);
 }
+
+int vit_set_batch_depth(int launches_in_flight) { return g_ring->set_depth(launches_in_flight); }
+
+int vit_set_batch_spin_cpus(int cpus) { return g_ring->spin_cpus.exchange(cpus < 0 ? 0 : cpus); }
 
 int vit_set_kernel(int which) {
     if (which < K_AUTO || which > K_PACKED8) which = K_AUTO;
@@ -651,21 +993,25 @@ static int deconvolve_impl(unsigned int framebits, unsigned int* symbols, unsign
         set_err("deconvolve: bad arguments (framebits=%u)", framebits);
         return 1;
     }
-    if (hip_device_ready() != VIT_OK) return 1;  // before should_batch(): a caller it has counted must reach submit()
-    InflightGuard inflight(g_batcher->inflight);
-    if (g_batcher->should_batch()) {
-        if (g_batcher->submit(framebits, symbols, decodedBits) != VIT_OK) {
+    if (hip_device_ready() != VIT_OK) return 1;
+    InflightGuard inflight(g_ring->inflight);
+    const DecodeMode mode = decode_mode();
+    if (g_ring->engaged(mode)) {  // ingest stage: share a launch with the other callers in flight
+        const int r = g_ring->call(mode, framebits, symbols, decodedBits);
+        if (r == RING_OK) return 0;
+        if (r == RING_FAILED) {
             g_fault.store(1);
             return 1;
         }
-        return 0;
+        // declined (no free slot, comparator mode differs from the open batch's): the direct path below
     }
     VitDeviceGuard guard(g_device);
     if (ctx_prepare(g_device) != VIT_OK) return 1;
     const size_t nsym = 4u * ((size_t)framebits + VIT_TAIL);
     const size_t out_sz = (framebits + 7u) >> 3;
-    int rc;
-    if ((rc = grow_pin(nsym * 4 + out_sz + 192)) != VIT_OK || (rc = grow_dev(&t_ctx.d_sym8, &t_ctx.d8_cap, nsym)) != VIT_OK) {
+    const size_t out_off = (nsym + 15u) & ~(size_t)15u;
+    const size_t flag_off = (out_off + out_sz + 63u) & ~(size_t)63u;
+    if (grow_pin(flag_off + 64) != VIT_OK) {
         g_fault.store(1);
         return 1;
     }
@@ -674,24 +1020,21 @@ static int deconvolve_impl(unsigned int framebits, unsigned int* symbols, unsign
         g_fault.store(1);
         return 1;
     };
-    // Zero-copy staging: the pinned buffer is mapped into the device's address space.  The decode kernel reads
-    // the caller's u32 symbols straight from host memory (12 KB over PCIe; its pre-pass loads run 32 steps
-    // ahead of their use, which covers the PCIe latency) and writes its (framebits+7)/8 bytes straight back:
-    // no hipMemcpy round trips, ONE launch, one sync.  (With the wave-per-frame kernel selected the ingest
-    // kernel narrows the symbols first.)
-    unsigned char* h_out = (unsigned char*)t_ctx.h_pin + nsym * 4;
-    memcpy(t_ctx.h_pin, symbols, nsym * 4);
-    const DecodeMode mode = decode_mode();
+    // Zero-copy staging: the pinned buffer is mapped into the device's address space.  The caller's u32 symbols are
+    // narrowed to the device format (one byte each, the low byte: deconvolve.cpp:158-165) while they are copied into
+    // it; the decode kernel reads those 3 KB (FIC) straight from host memory, in one batch of loads, and writes its
+    // (framebits+7)/8 bytes straight back: no hipMemcpy round trips, ONE launch, one wait.
+    unsigned char* h_out = (unsigned char*)t_ctx.h_pin + out_off;
+    narrow_symbols(symbols, (uint8_t*)t_ctx.h_pin, nsym);
     hipError_t e;
     if (pick_kernel(mode.kernel, framebits, 1) == K_LATENCY) {
         // Latency path: the kernel publishes a sequence number in the mapped buffer after its last output byte and
         // this thread spins on it - the end-of-kernel signal and hipStreamSynchronize's wake-up are off the call's
         // critical path.  A kernel that does not finish within the spin budget falls back to the stream sync.
-        const size_t flag_off = (nsym * 4 + out_sz + 63u) & ~(size_t)63u;
         volatile uint32_t* h_flag = reinterpret_cast<volatile uint32_t*>((unsigned char*)t_ctx.h_pin + flag_off);
         const uint32_t seq = ++t_ctx.seq ? t_ctx.seq : ++t_ctx.seq;  // never 0
         *h_flag = 0;
-        e = vit_launch_lat(t_ctx.h_pin_dev, true, (uint8_t*)t_ctx.h_pin_dev + nsym * 4, nullptr, framebits, framebits, 1,
+        e = vit_launch_lat(t_ctx.h_pin_dev, false, (uint8_t*)t_ctx.h_pin_dev + out_off, nullptr, framebits, framebits, 1,
                            t_ctx.stream, reinterpret_cast<uint32_t*>((unsigned char*)t_ctx.h_pin_dev + flag_off), seq, mode.ge);
         if (e != hipSuccess) return fail("launch", e);
         const auto t0 = std::chrono::steady_clock::now();
@@ -711,8 +1054,8 @@ static int deconvolve_impl(unsigned int framebits, unsigned int* symbols, unsign
         memcpy(decodedBits, h_out, out_sz);
         return 0;
     }
-    if (launch_decode_u32(mode, (const uint32_t*)t_ctx.h_pin_dev, (uint8_t*)t_ctx.d_sym8, (uint8_t*)t_ctx.h_pin_dev + nsym * 4,
-                          nullptr, framebits, framebits, 1, (int64_t)nsym, t_ctx.stream) != VIT_OK) {
+    if (launch_decode(mode, (const uint8_t*)t_ctx.h_pin_dev, (uint8_t*)t_ctx.h_pin_dev + out_off, nullptr, framebits, framebits, 1,
+                      t_ctx.stream) != VIT_OK) {
         g_fault.store(1);
         return 1;
     }

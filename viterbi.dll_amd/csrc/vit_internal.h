@@ -36,6 +36,20 @@ hipError_t vit_launch_pk8(const void* d_symbols, bool sym32, uint8_t* d_out, con
 hipError_t vit_launch_lat(const void* d_symbols, bool sym32, uint8_t* d_out, const vit_frame_desc* d_desc,
                           uint32_t framebits, uint32_t max_framebits, int64_t nframes,
                           hipStream_t stream, uint32_t* done_flag, uint32_t done_seq, bool renorm_ge);
+// Ingest-stage launch (vit_api.hip): one frame per slot of a mapped pinned ring.  The table travels BY VALUE in the
+// kernel arguments (no descriptor fetch over PCIe in front of the symbol loads).
+#define VIT_RING_MAXB 128u  // frames per launch
+struct VitRingTable {
+    uint32_t n;         // frames of this launch (= grid)
+    uint32_t seq;       // what every slot's completion word receives (never 0)
+    uint32_t stride;    // bytes per slot
+    uint32_t out_off;   // offset of a slot's (framebits+7)/8 output bytes
+    uint32_t flag_off;  // offset of a slot's completion word
+    uint16_t slot[VIT_RING_MAXB];
+    uint16_t fb[VIT_RING_MAXB];  // framebits of the frame in that slot (even, 2..9216)
+};
+hipError_t vit_launch_lat_ring(uint8_t* d_ring, const VitRingTable& tbl, uint32_t max_framebits, hipStream_t stream,
+                               bool renorm_ge);
 // frames the latency kernel can keep resident at one wave per SIMD or so for this frame length (LDS-limited)
 int64_t vit_lat_capacity(uint32_t max_framebits, int dev);
 // Length-sorted (longest first) copy of a device descriptor table; d_bins = 2*VIT_SORT_BINS words of scratch.

@@ -49,6 +49,17 @@ DEV void met8(u32 s, u32& lo, u32& hi) {
     hi = (avg4(P, qhi) >> 2) & 0x3F3F3F3Fu;
 }
 
+// Diagnostic builds only (tools/probe/lat_phases.hip defines VIT_LAT_STAMPS): shader-clock stamps at the phase borders
+#ifdef VIT_LAT_STAMPS
+__device__ unsigned long long g_lat_stamps[16];
+#define LAT_STAMP(k)                                                     \
+    do {                                                                 \
+        if (threadIdx.x == 0 && blockIdx.x == 0) g_lat_stamps[k] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define LAT_STAMP(k) do {} while (0)
+#endif
+
 constexpr u32 CHUNK = 96;       // steps per pre-pass and per unrolled ACS body: a multiple of 6 (phases) and 32 (history words)
 constexpr u32 TB_WARM = 30;     // warm-up steps of a speculative traceback block (multiple of 6)
 
@@ -150,20 +161,8 @@ struct ChunkSteps<(int)CHUNK> {
     }
 };
 
-template <bool SYM32>
-__global__ __launch_bounds__(64) void vit_lat_kernel(const uint8_t* __restrict__ sym, uint8_t* __restrict__ out,
-                                                     const vit_frame_desc* __restrict__ desc, u32 framebits_uniform,
-                                                     u32 max_framebits, long long nframes, LatLayout lay,
-                                                     u32* done_flag, u32 done_seq, u32 renorm_thr) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    u32* symb = reinterpret_cast<u32*>(lds + lay.sym_off);
-    char* tab = lds + lay.tab_off;
-    u32* dec = reinterpret_cast<u32*>(lds + lay.dec_off);
-    u32* img = reinterpret_cast<u32*>(lds + lay.img_off);
-    const u32 lane = threadIdx.x;
-
-    // class of this lane's butterfly per phase: state bit k sits in lane bit (k - rho) mod 6
-    u32 toff[6];
+// class of this lane's butterfly per phase: state bit k sits in lane bit (k - rho) mod 6
+DEV void lat_class_offsets(u32 lane, u32 (&toff)[6]) {
 #pragma unroll
     for (int rho = 0; rho < 6; rho++) {
         u32 i = 0;
@@ -173,21 +172,20 @@ __global__ __launch_bounds__(64) void vit_lat_kernel(const uint8_t* __restrict__
         const u32 c = (i1 ^ i2 ^ i4) | ((i0 ^ i1 ^ i2) << 1) | ((i0 ^ i3) << 2);  // parity((2i) & poly_j), const.asm:27-63
         toff[rho] = c * 8u;
     }
+}
 
-    for (long long f = blockIdx.x; f < nframes; f += gridDim.x) {
-        u32 fb = framebits_uniform;
-        size_t soff, ooff;
-        if (desc) {
-            fb = desc[f].framebits;
-            soff = desc[f].sym_offset;
-            ooff = desc[f].out_offset;
-            if (fb > max_framebits || (fb & 1u) || (soff & 3u)) continue;  // not what the launch was sized for
-        } else {
-            soff = (size_t)f * 4u * (fb + VIT_TAIL);
-            ooff = (size_t)f * ((fb + 7u) >> 3);
-        }
-        if (fb == 0) continue;
+// One frame on one wavefront: `sym` + soff = its symbols (soff counts bytes for the u8 format, symbols for u32),
+// o = its (fb+7)/8 output bytes, fb even and 0 < fb <= the framebits `lay` was sized for.
+template <bool SYM32>
+DEV void lat_decode_frame(const uint8_t* __restrict__ sym, size_t soff, uint8_t* __restrict__ o, u32 fb,
+                          const LatLayout& lay, char* lds, const u32 (&toff)[6], u32 lane, u32 renorm_thr) {
+    u32* symb = reinterpret_cast<u32*>(lds + lay.sym_off);
+    char* tab = lds + lay.tab_off;
+    u32* dec = reinterpret_cast<u32*>(lds + lay.dec_off);
+    u32* img = reinterpret_cast<u32*>(lds + lay.img_off);
+    {
         const u32 T = fb + VIT_TAIL;
+        LAT_STAMP(0);
 
         // ---- stage the frame's symbols: one dword (4 soft symbols, low bytes) per step ----
         // All loads of a batch of 16 x 64 steps are issued before the first one is consumed: a FIC frame costs ONE
@@ -227,6 +225,7 @@ __global__ __launch_bounds__(64) void vit_lat_kernel(const uint8_t* __restrict__
         }
         for (u32 i = lane; i < ((fb + 31u) >> 5) + 2u; i += 64u) img[i] = 0;
         __syncthreads();
+        LAT_STAMP(1);
 
         // ---- ACS ----
         u32 m = lane == 0 ? 0u : 63u;  // const.asm:19-25 (0-based; step 0 is even)
@@ -257,6 +256,7 @@ __global__ __launch_bounds__(64) void vit_lat_kernel(const uint8_t* __restrict__
             ChunkSteps<0>::run(m, acc, pd, tab, toff, lane, dec + ch * (CHUNK / 32u) * 64u + lane, renorm_thr);
         }
         __syncthreads();
+        LAT_STAMP(2);
 
         // ---- traceback: lane q takes steps [6 + q*BL, 6 + (q+1)*BL) ----
         // One step back from time t: j = (5 - t) mod 6, the decision d of the state on the path (lane L) is
@@ -300,6 +300,7 @@ __global__ __launch_bounds__(64) void vit_lat_kernel(const uint8_t* __restrict__
         u32 L_in = L;
         trace(L, (int)BL - 1, 0, has_work, i_start, true);
         if (has_work) L_out = L;
+        LAT_STAMP(3);
         for (int pass = 0; pass < 65; pass++) {
             const u32 nxt = __shfl_down(L_out, 1);
             const u32 new_in = (lane < q_top) ? nxt : 0u;
@@ -310,6 +311,7 @@ __global__ __launch_bounds__(64) void vit_lat_kernel(const uint8_t* __restrict__
             trace(L, (int)BL - 1, 0, changed, BL - 1u, true);
             if (changed) L_out = L;
         }
+        LAT_STAMP(4);
         if (has_work) {
             const u32 nvalid = i_last + 1u < BL ? i_last + 1u : BL;
             const u32 b0 = lane * BL;  // decoded bit index of the block's first step
@@ -329,7 +331,6 @@ __global__ __launch_bounds__(64) void vit_lat_kernel(const uint8_t* __restrict__
         __syncthreads();
         // bit b of the image is decoded bit b; output bytes are MSB-first (deconvolve.cpp:432-433)
         const u32 nbytes = (fb + 7u) >> 3;
-        uint8_t* o = out + ooff;
         if (((reinterpret_cast<uintptr_t>(o) | nbytes) & 3u) == 0) {
             for (u32 k = lane; k < (nbytes >> 2); k += 64u)
                 reinterpret_cast<u32*>(o)[k] = __builtin_bswap32(__builtin_bitreverse32(img[k]));
@@ -340,12 +341,59 @@ __global__ __launch_bounds__(64) void vit_lat_kernel(const uint8_t* __restrict__
             }
         }
         __syncthreads();
+        LAT_STAMP(5);
+    }
+}
+
+template <bool SYM32>
+__global__ __launch_bounds__(64) void vit_lat_kernel(const uint8_t* __restrict__ sym, uint8_t* __restrict__ out,
+                                                     const vit_frame_desc* __restrict__ desc, u32 framebits_uniform,
+                                                     u32 max_framebits, long long nframes, LatLayout lay,
+                                                     u32* done_flag, u32 done_seq, u32 renorm_thr) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const u32 lane = threadIdx.x;
+    u32 toff[6];
+    lat_class_offsets(lane, toff);
+
+    for (long long f = blockIdx.x; f < nframes; f += gridDim.x) {
+        u32 fb = framebits_uniform;
+        size_t soff, ooff;
+        if (desc) {
+            fb = desc[f].framebits;
+            soff = desc[f].sym_offset;
+            ooff = desc[f].out_offset;
+            if (fb > max_framebits || (fb & 1u) || (soff & 3u)) continue;  // not what the launch was sized for
+        } else {
+            soff = (size_t)f * 4u * (fb + VIT_TAIL);
+            ooff = (size_t)f * ((fb + 7u) >> 3);
+        }
+        if (fb == 0) continue;
+        lat_decode_frame<SYM32>(sym, soff, out + ooff, fb, lay, lds, toff, lane, renorm_thr);
     }
     // Completion flag for the single-call path (deconvolve()): the host spins on a word of its mapped staging
     // buffer instead of waiting for the end-of-kernel signal.  Every output byte of this wave is written (and
     // made visible system-wide by the release) before the flag.
     if (done_flag && lane == 0)
         __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Ingest-stage launch (vit_api.hip): workgroup b decodes the frame a deconvolve() caller has put into
+// slot tbl.slot[b] of the mapped pinned ring (symbols already narrowed to one byte each by the caller's copy) and
+// publishes the batch's sequence number in the slot's completion word after its last output byte, with system
+// scope - the caller spins on that word.  One bounded launch per batch, no polling on the device.
+__global__ __launch_bounds__(64) void vit_lat_ring_kernel(uint8_t* __restrict__ ring, VitRingTable tbl, LatLayout lay,
+                                                          u32 renorm_thr) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const u32 lane = threadIdx.x;
+    const u32 b = blockIdx.x;
+    if (b >= tbl.n) return;
+    u32 toff[6];
+    lat_class_offsets(lane, toff);
+    const u32 slot = tbl.slot[b], fb = tbl.fb[b];
+    uint8_t* base = ring + (size_t)slot * tbl.stride;
+    lat_decode_frame<false>(base, 0, base + tbl.out_off, fb, lay, lds, toff, lane, renorm_thr);
+    if (lane == 0)
+        __hip_atomic_store(reinterpret_cast<u32*>(base + tbl.flag_off), tbl.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace
@@ -379,5 +427,25 @@ hipError_t vit_launch_lat(const void* d_symbols, bool sym32, uint8_t* d_out, con
     else
         hipLaunchKernelGGL(vit_lat_kernel<false>, dim3((unsigned)grid), dim3(64), lay.total, stream, d_sym, d_out, d_desc,
                            framebits, max_framebits, (long long)nframes, lay, done_flag, done_seq, thr);
+    return hipGetLastError();
+}
+
+hipError_t vit_launch_lat_ring(uint8_t* d_ring, const VitRingTable& tbl, uint32_t max_framebits, hipStream_t stream,
+                               bool renorm_ge) {
+    if (tbl.n == 0) return hipSuccess;
+    if (tbl.n > VIT_RING_MAXB || (reinterpret_cast<uintptr_t>(d_ring) & 15u) || (tbl.stride & 15u) || (tbl.out_off & 3u) ||
+        (tbl.flag_off & 3u))
+        return hipErrorInvalidValue;
+    for (u32 i = 0; i < tbl.n; i++)
+        if (tbl.fb[i] == 0 || tbl.fb[i] > max_framebits || (tbl.fb[i] & 1u)) return hipErrorInvalidValue;
+    static uint64_t optin_done = 0;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const void* ks[1] = {reinterpret_cast<const void*>(vit_lat_ring_kernel)};
+    if ((e = vit_optin_dynamic_lds(ks, 1, 160 * 1024, dev, &optin_done)) != hipSuccess) return e;
+    const LatLayout lay = lat_layout(max_framebits);
+    hipLaunchKernelGGL(vit_lat_ring_kernel, dim3(tbl.n), dim3(64), lay.total, stream, d_ring, tbl, lay,
+                       renorm_ge ? 149u : 150u);
     return hipGetLastError();
 }

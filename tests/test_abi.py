@@ -105,4 +105,4 @@ def test_ingest_stage_environment_knobs():
     out = subprocess.check_output([sys.executable, "-c", code], env=clean, text=True)
     ncpu = len(os.sched_getaffinity(0))
     m = re.search(r"RESULT 50 1 4 5 16 1 (\d+) 7 0", out)
-    assert m and 1 <= int(m.group(1)) <= ncpu  # affinity mask, capped by a cgroup CPU quota
+    assert m and 0 <= int(m.group(1)) <= ncpu // 4  # a quarter of: affinity mask, capped by a cgroup CPU quota

@@ -42,6 +42,32 @@ def test_decode_stream_multi_matches_oracle(V, O, torch_cuda, fb, n, chunk, root
     assert torch.cuda.current_device() == 0  # the caller's device is restored
 
 
+def test_decode_stream_multi_error_between_group_start_and_end(V, O, torch_cuda):
+    """fault injection on the loop-back path: an error return inside a send/recv group closes the group, ABORTS the
+    communicators (no wait for transfers that may never complete), drops the context - and the next call rebuilds it
+    and decodes correctly"""
+    torch = torch_cuda
+    fb, n = 768, 3000
+    sym = _frames(O, n, fb, seed=5)
+    want = O.decode_batch(fb, sym, nthreads=8)
+    d_sym = torch.from_numpy(sym).cuda()
+    d_out = torch.full((n, fb // 8), 0xEE, dtype=torch.uint8, device="cuda")
+    dev = [torch.cuda.current_device()]
+    V.decode_stream_multi(d_sym, d_out, fb, n, dev, 256, -1, V.MULTI_LOOPBACK)
+    assert np.array_equal(d_out.cpu().numpy(), want)
+    os.environ["VITERBI_AMD_TEST_MULTI_FAULT"] = "2"
+    try:
+        with pytest.raises(V.ViterbiError, match="injected fault"):
+            V.decode_stream_multi(d_sym, d_out, fb, n, dev, 256, -1, V.MULTI_LOOPBACK)
+    finally:
+        del os.environ["VITERBI_AMD_TEST_MULTI_FAULT"]
+    torch.cuda.synchronize()
+    d_out.fill_(0xEE)
+    V.decode_stream_multi(d_sym, d_out, fb, n, dev, 256, -1, V.MULTI_LOOPBACK)
+    assert np.array_equal(d_out.cpu().numpy(), want)
+    assert torch.cuda.current_device() == 0
+
+
 def test_decode_stream_multi_rejects_bad_arguments(V, torch_cuda):
     torch = torch_cuda
     d = torch.zeros(4 * 774 * 4, dtype=torch.uint8, device="cuda")

@@ -1,4 +1,5 @@
-"""GPU parity of the 8-frames-per-wavefront packed kernel (csrc/vit_pk8.hip, vit_set_kernel(4)) against the oracle:
+"""GPU parity of the 8-frames-per-wavefront packed kernel (csrc/vit_pk8.hip, vit_set_kernel(4); an experiment that is
+compiled in only with -DVIT_WITH_PK8 - skipped against the product library) against the oracle:
 every length of one segment (<= 778 bits), ragged batches, both renormalise comparators, hard-decision and saturation
 inputs, u32 ingest, descriptor tables.  Bit-exact, through the C ABI."""
 import numpy as np
@@ -6,6 +7,16 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 K8 = 4
+
+
+@pytest.fixture(autouse=True)
+def _needs_pk8(V):
+    """the experiment is not part of the product library: these tests run only against a build with -DVIT_WITH_PK8
+    (python -c "import _vitpkg; _vitpkg.load_package().build(force=True, extra=['-DVIT_WITH_PK8'])")"""
+    old = V.set_kernel(K8)
+    have = V.set_kernel(old) == K8  # without the kernel vit_set_kernel(4) selects 0
+    if not have:
+        pytest.skip("libviterbi.so was built without -DVIT_WITH_PK8 (the 8-frames-per-wavefront experiment)")
 
 
 def _decode(V, torch, sym, framebits, kernel=K8):

@@ -44,12 +44,12 @@ DESC_DTYPE = np.dtype([("sym_offset", "<u8"), ("out_offset", "<u8"), ("framebits
 _lib = None
 
 
-def build(force=False):
+def build(force=False, extra=(), out=None):
     from importlib import util as _u
     spec = _u.spec_from_file_location("_vit_build", os.path.join(_HERE, "build.py"))
     mod = _u.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    return mod.build(force=force)
+    return mod.build(force=force, extra=extra, out=out)
 
 
 def lib():

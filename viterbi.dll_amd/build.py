@@ -7,7 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libviterbi.so")
-SOURCES = ["vit_api.hip", "vit_wave.hip", "vit_pk.hip", "vit_pk8.hip", "vit_sort.hip", "rs_kernels.hip", "vit_multi.hip", "vit_lat.hip"]
+SOURCES = ["vit_api.hip", "vit_wave.hip", "vit_pk.hip", "vit_sort.hip", "rs_kernels.hip", "vit_multi.hip", "vit_lat.hip"]
+PK8_SOURCE = "vit_pk8.hip"  # round-3 experiment (8 frames per wavefront, slower): only with extra=["-DVIT_WITH_PK8"]
 DEPS = SOURCES + ["vit_internal.h", "vit_pk_dev.h", "exports.map"]
 
 
@@ -28,7 +29,7 @@ def build(force=False, verbose=False, extra=(), out=None):
            "-Wall", "-Wno-unused-function",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC,
            "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"),
-           "-o", out or SO] + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
+           "-o", out or SO] + list(extra) + [os.path.join(CSRC, s) for s in SOURCES + ([PK8_SOURCE] if "-DVIT_WITH_PK8" in extra else [])] + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -220,11 +220,12 @@ bool valid_framebits(uint32_t fb) { return fb <= VIT_MAX_FRAMEBITS && (fb & 1u) 
 // vit_set_kernel() READ ONCE by the exported entry point (a concurrent vit_set_kernel must not flip the decision
 // between the check that sizes the scratch buffers and the launch).
 enum { K_AUTO = 0, K_WAVE = 1, K_PACKED = 2, K_LATENCY = 3, K_PACKED8 = 4 };
-// Frames of one segment (<= 778 bits) in a uniform-length batch have two packed kernels: 4 frames per wavefront at 4
-// wavefronts per SIMD (vit_pk.hip) and 8 frames per wavefront at 2 per SIMD (vit_pk8.hip).  The second executes 12 % fewer
-// instructions per frame (8 % fewer than the shipped kernel since its fast traceback form) and is 14 % SLOWER on the benchmark batch (two wavefronts cannot hide the LDS round trips of the
-// exchange and of the traceback: profiles/r03_ab_pk8.txt), so it is not the default: VITERBI_AMD_PK8=1 makes K_AUTO /
-// K_PACKED take it, vit_set_kernel(4) forces it (tests, A/B runs).
+// The 8-frames-per-wavefront kernel (vit_pk8.hip; round 3: 12 % fewer instructions per frame, 19 % slower than vit_pk.hip -
+// two wavefronts per SIMD cannot hide the LDS round trips, profiles/r03_ab_pk8.txt) is an experiment: it is compiled in
+// only with -DVIT_WITH_PK8 (viterbi.dll_amd/build.py: build(extra=["-DVIT_WITH_PK8"])).  The product library does not
+// carry it: vit_set_kernel(4) then selects 0 (auto).
+#ifdef VIT_WITH_PK8
+constexpr int K_MAX = K_PACKED8;
 bool pk8_default() {
     static const bool on = [] {
         const char* e = getenv("VITERBI_AMD_PK8");
@@ -232,6 +233,10 @@ bool pk8_default() {
     }();
     return on;
 }
+#else
+constexpr int K_MAX = K_LATENCY;
+bool pk8_default() { return false; }
+#endif
 // which kernel runs a batch: the explicit choice, or for K_AUTO the latency kernel for launches that cannot fill
 // the chip (<= VIT_LAT_MAX_FRAMES wavefronts) and the packed kernel otherwise
 int pick_kernel(int choice, uint32_t max_framebits, int64_t nframes) {
@@ -455,7 +460,10 @@ struct Ring {
             min_callers.store(n < 1 ? 1 : n);
         }
         if (const char* e = getenv("VITERBI_AMD_BATCH_DEPTH")) set_depth(atoi(e));
-        if (const char* e = getenv("VITERBI_AMD_SPIN_CPUS")) spin_cpus.store(atoi(e) < 0 ? 0 : atoi(e));
+        // waiting callers spin only while the calls in flight use at most a quarter of the process's CPU budget
+        // (profiles/r04_vitbench_sweep.txt: spinning up to the whole budget throttles a quota-limited container)
+        const char* e = getenv("VITERBI_AMD_SPIN_CPUS");
+        spin_cpus.store(e ? (atoi(e) < 0 ? 0 : atoi(e)) : detect_cpu_budget() / 4);
     }
     int set_depth(int n) { return depth.exchange(n < 1 ? 1 : n > RING_MAX_DEPTH ? RING_MAX_DEPTH : n); }
     int take_token() {  // -1: `depth` batches are in flight
@@ -633,10 +641,7 @@ int Ring::wait_done(RingBatch* b, uint32_t idx, uint32_t* flag, uint32_t my_seq,
 }
 
 int Ring::call(const DecodeMode& mode, uint32_t framebits, const unsigned int* symbols, unsigned char* out) {
-    std::call_once(once, [this] {
-        if (spin_cpus.load() == 0 && !getenv("VITERBI_AMD_SPIN_CPUS")) spin_cpus.store(detect_cpu_budget() / 4);
-        allocate();
-    });
+    std::call_once(once, [this] { allocate(); });
     if (init_rc != VIT_OK) return RING_DECLINED;
     const bool st = g_rstat.on;
     const uint64_t t_in = st ? RingStats::now() : 0;
@@ -764,6 +769,13 @@ struct InflightGuard {
 
 }  // namespace
 
+#ifndef VIT_WITH_PK8  // the experiment is not compiled in: the launcher's names exist, the kernel does not
+bool vit_pk8_supported(uint32_t) { return false; }
+hipError_t vit_launch_pk8(const void*, bool, uint8_t*, const vit_frame_desc*, uint32_t, uint32_t, int64_t, hipStream_t, bool) {
+    return hipErrorNotSupported;
+}
+#endif
+
 void vit_set_err(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -824,7 +836,7 @@ int vit_set_batch_depth(int launches_in_flight) { return g_ring->set_depth(launc
 int vit_set_batch_spin_cpus(int cpus) { return g_ring->spin_cpus.exchange(cpus < 0 ? 0 : cpus); }
 
 int vit_set_kernel(int which) {
-    if (which < K_AUTO || which > K_PACKED8) which = K_AUTO;
+    if (which < K_AUTO || which > K_MAX) which = K_AUTO;
     return g_kernel.exchange(which);
 }
 

@@ -26,6 +26,7 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
                          uint32_t framebits, uint32_t max_framebits, int64_t nframes,
                          hipStream_t stream, bool renorm_ge);
 // Packed kernel, 8 frames per wavefront at 2 wavefronts per SIMD (vit_pk8.hip): frames of one segment (framebits <= 778).
+// An experiment, compiled in only with -DVIT_WITH_PK8 (otherwise vit_api.hip holds stubs that report "not supported").
 bool vit_pk8_supported(uint32_t max_framebits);
 hipError_t vit_launch_pk8(const void* d_symbols, bool sym32, uint8_t* d_out, const vit_frame_desc* d_desc,
                           uint32_t framebits, uint32_t max_framebits, int64_t nframes, hipStream_t stream, bool renorm_ge);

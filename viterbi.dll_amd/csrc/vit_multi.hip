@@ -35,6 +35,7 @@ struct Rccl {
     void* handle = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;  // optional
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -65,6 +66,7 @@ struct Rccl {
         VIT_SYM(GroupEnd, "ncclGroupEnd")
         VIT_SYM(GetErrorString, "ncclGetErrorString")
 #undef VIT_SYM
+        CommAbort = reinterpret_cast<decltype(CommAbort)>(dlsym(handle, "ncclCommAbort"));
         return true;
     }
 };
@@ -87,6 +89,7 @@ struct MultiCtx {
     std::vector<Rank> ranks;  // ranks[0] = root
     hipEvent_t ev_in = nullptr;
     bool ready = false;
+    bool group_failed = false;  // a send/recv group was closed on an error path: it may hold unmatched transfers
 };
 
 std::mutex g_mu;  // one multi-device call at a time
@@ -123,8 +126,10 @@ void destroy_ctx(MultiCtx& c) {
         if (r.own_sx && r.s_x) (void)hipStreamDestroy(r.s_x);
     }
     if (c.ev_in) (void)hipEventDestroy(c.ev_in);
+    // After a group that was closed on an error path the communicators may hold transfers whose partner was never
+    // posted: ncclCommDestroy would wait for them, ncclCommAbort ends them (round-3 advisor finding).
     for (ncclComm_t cm : c.comms)
-        if (cm) (void)g_rccl.CommDestroy(cm);
+        if (cm) (void)((c.group_failed && g_rccl.CommAbort) ? g_rccl.CommAbort(cm) : g_rccl.CommDestroy(cm));
     c = MultiCtx();
 }
 
@@ -237,11 +242,19 @@ int run(const uint8_t* d_sym, uint8_t* d_out, uint32_t framebits, int64_t nframe
             // an error return between GroupStart and GroupEnd must still close the group: RCCL's group depth is
             // per thread, and the clean-up after a failed call (ncclCommDestroy) runs on this thread
             struct GroupGuard {
+                MultiCtx& ctx;
                 bool open = true;
                 ~GroupGuard() {
-                    if (open) (void)g_rccl.GroupEnd();
+                    if (!open) return;
+                    ctx.group_failed = true;  // the exported call aborts the communicators before it waits for anything
+                    (void)g_rccl.GroupEnd();
                 }
-            } group;
+            } group{c};
+            // TEST HOOK (tests/test_gpu_multi.py): VITERBI_AMD_TEST_MULTI_FAULT=<j> fails transfer step j after its first
+            // complete send/recv pair, i.e. on the error path between GroupStart and GroupEnd
+            const char* fault_env = getenv("VITERBI_AMD_TEST_MULTI_FAULT");
+            const int64_t fault_at = fault_env ? atoll(fault_env) : -1;
+            bool posted = false;
             for (int r = 1; r < W; r++) {
                 Rank& k = c.ranks[(size_t)r];
                 int64_t lo, n;
@@ -249,6 +262,11 @@ int run(const uint8_t* d_sym, uint8_t* d_out, uint32_t framebits, int64_t nframe
                 if (n) {
                     MNCCL(g_rccl.Send(d_sym + (size_t)lo * symlen, (size_t)n * symlen, ncclUint8, k.comm, c.comms[0], root.s_x));
                     MNCCL(g_rccl.Recv(k.rbuf[h], (size_t)n * symlen, ncclUint8, 0, c.comms[(size_t)k.comm], k.s_x));
+                    posted = true;
+                }
+                if (posted && fault_at == j) {
+                    vit_set_err("vit_decode_stream_multi: injected fault in transfer step %lld (VITERBI_AMD_TEST_MULTI_FAULT)", (long long)j);
+                    return VIT_ERR_HIP;
                 }
                 P.block(j - 2, r, &lo, &n);
                 if (n) {
@@ -333,6 +351,10 @@ extern "C" int vit_decode_stream_multi(const uint8_t* d_symbols_u8, uint8_t* d_d
     int rc = build_ctx(devices, ndev, loopback);
     if (rc == VIT_OK) rc = run(d_symbols_u8, d_decoded, framebits, nframes, P, (hipStream_t)stream);
     if (rc != VIT_OK) {  // drain whatever was enqueued, drop the context: the next call starts clean
+        if (g_ctx.group_failed && g_rccl.CommAbort) {  // first end transfers that may never find their partner
+            for (ncclComm_t& cm : g_ctx.comms)
+                if (cm) { (void)g_rccl.CommAbort(cm); cm = nullptr; }
+        }
         for (int i = 0; i < ndev; i++)
             if (hipSetDevice(devices[i]) == hipSuccess) (void)hipDeviceSynchronize();
         destroy_ctx(g_ctx);

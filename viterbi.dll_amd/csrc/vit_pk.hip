@@ -114,7 +114,7 @@ DEV u32 acs_l5(u32 lane) { return VIT_PAIR_LSB ? lane >> 1 : lane & 31u; }
 DEV u32 acs_pair(u32 lane) { return VIT_PAIR_LSB ? lane & 1u : lane >> 5; }
 // toff by lane, tabulated at compile time (80 VALU instructions per wave as arithmetic; two loads that are back long before the
 // first table read).  Butterfly index of ACS lane l5 at phase rho = rol5(l5, rho); its class = parity((2i) & poly_j), const.asm:27-63.
-struct ToffTable {
+struct alignas(32) ToffTable {  // load_toff reads a row with one 16-byte load
     u32 v[64][8];  // [lane][rho], rows padded to 32 bytes
 };
 constexpr ToffTable make_toff_table() {

@@ -393,6 +393,8 @@ def scatter_leg(args, dist, sharding, rank, world, dev, d_sym, d_out, decode_int
     def step():
         sharding.decode_stream(d_all, d_all_out, n_total, FRAMEBITS, decode_into, chunk, rootf)
 
+    if os.environ.get("VIT_BENCH_TEST_HANG_SCATTER") and rank == world - 1:
+        time.sleep(3600)  # TEST HOOK (tests/test_bench_launcher.py): one rank never reaches the collective - what a hung RCCL leg looks like
     step()  # warm-up: buffers, communicator channels
     sync()
     dist.barrier()

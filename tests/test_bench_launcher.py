@@ -51,6 +51,21 @@ def test_n_gt_1_record_describes_itself():
     assert "scatter" not in _run(["--gpus", "2", "--mode", "scatter", "--chunk-frames", "10"])
 
 
+def test_hung_scatter_leg_is_a_failure_with_the_shard_line_intact():
+    """a collective leg that does not come back: the watchdog prints the shard line WITH the error in it and every rank
+    exits non-zero (round-3 advisor: a hang must not end as rc 0)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["VIT_BENCH_TEST_HANG_SCATTER"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "gloo", "--stub", "--steps", "2",
+                        "--warmup", "1", "--frames", "48", "--gpus", "2", "--scatter-timeout", "5"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 3, (p.returncode, p.stderr[-2000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["value"] > 0 and "did not finish" in r["scatter"]["error"]
+
+
 def test_three_ranks_and_forced_spawn_of_one():
     assert _run(["--gpus", "3", "--mode", "scatter", "--chunk-frames", "7"])["n_gpus"] == 3
     r = _run(["--gpus", "1", "--spawn"])

@@ -778,3 +778,26 @@ def test_full_size_fic_batch_properties(V, O, torch_cuda):
     got = d_out.view(reps, base_n, framebits // 8)
     d_want = torch.from_numpy(want).cuda()
     assert bool((got == d_want.unsqueeze(0)).all())
+
+
+def test_full_size_fic_batch_ge_mode(V, O, torch_cuda):
+    """BASELINE config 2 (65536 FIC frames) with the MASM decoders' `>= 150` comparator (vit_set_renorm_ge(1)): the
+    batch is tiled from 256 distinct frames - soft-decision ones and the two hard-decision families on which the two
+    comparators give different outputs (asserted) - and every tile must equal the ge oracle's decode."""
+    torch = torch_cuda
+    framebits, base_n, reps = 768, 256, 256
+    base = np.concatenate([_mixed_input(O, base_n // 2, framebits, seed=77), _hard_families(O, framebits, base_n // 4, seed=78)])
+    assert base.shape[0] == base_n
+    want_ge = O.decode_batch(framebits, base, nthreads=8, ge=True)
+    want_gt = O.decode_batch(framebits, base, nthreads=8)
+    assert (want_ge != want_gt).any(axis=1).sum() >= 2  # the mode matters on this batch
+    d_sym = torch.from_numpy(base).cuda().repeat(reps, 1).contiguous()
+    n = base_n * reps
+    old = V.set_renorm_ge(1)
+    try:
+        d_out = torch.zeros((n, framebits // 8), dtype=torch.uint8, device="cuda")
+        V.decode_batch_dev(d_sym, d_out, framebits, n)
+        torch.cuda.synchronize()
+    finally:
+        V.set_renorm_ge(old)
+    assert bool((d_out.view(reps, base_n, framebits // 8) == torch.from_numpy(want_ge).cuda().unsqueeze(0)).all())

@@ -190,15 +190,17 @@ int vit_set_kernel(int which);
 
 /* Renormalisation comparator of the decoder (process-wide, affects later vit_decode_* / deconvolve calls).
  * The reference exists in two build configurations that differ in ONE comparison on the hot path:
- *   0 (default): renormalise when the metric of state 0 is  > 150 -- the C decoders, deconvolve.cpp:399,408
- *                (configuration Rel_cpp, the one that can be compiled and run outside Windows);
- *   1          : renormalise when it is                    >= 150 -- the MASM decoders, decon_avx2.asm:97,114
+ *   1 (default): renormalise when the metric of state 0 is >= 150 -- the MASM decoders, decon_avx2.asm:97,114
  *                `cmp sil,150 ; jb mainloop` (also decon_avx.asm:142, decon_ssse3.asm:163,
- *                decon_sse2_lut32.asm:173; configuration Rel_asm, the DLL QIRX ships).
+ *                decon_sse2_lut32.asm:173; configuration Rel_asm, the one the reference's README tells users to
+ *                build (README.md:50-52): what an installed viterbi.dll runs);
+ *   0          : renormalise when it is                    >  150 -- the C decoders, deconvolve.cpp:399,408
+ *                (configuration Rel_cpp, the one that can be compiled and run outside Windows; bench.py selects it
+ *                because its timed CPU baseline, this repo's AVX2 port, implements it).
  * The two give identical output on soft-decision input at any usable SNR and DIFFERENT output on hard-decision
  * (0/255) input from a poor channel, where path metrics reach the 0 and 255 clamps (tests/test_gpu_parity.py:
- * test_renorm_ge_mode).  Environment variable VITERBI_AMD_RENORM_GE=1 selects mode 1 at start-up for a host that
- * only binds the five reference exports.  Returns the previous value. */
+ * test_renorm_ge_mode).  Environment variable VITERBI_AMD_RENORM_GE=0/1 selects the mode at start-up for a host that
+ * only binds the five reference exports.  Returns the previous value.  (Until round 3 the default was 0.) */
 int vit_set_renorm_ge(int on);
 
 /* ------------------------------------------------------------------------ *

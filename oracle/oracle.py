@@ -35,6 +35,7 @@ def lib():
         L.vo_deconvolve.argtypes = [C.c_uint, vp, C.c_int, vp]
         L.vo_deconvolve_opt.argtypes = [C.c_uint, vp, vp, C.c_int]
         L.vo_deconvolve_u8.argtypes = [C.c_uint, vp, vp]
+        L.vo_trace_state0_u8.argtypes = [C.c_uint, vp, C.c_int, vp]
         L.vo_decode_batch_u8.argtypes = [C.c_uint, vp, vp, C.c_long, C.c_int]
         L.vo_decode_batch_u8_opt.argtypes = [C.c_uint, vp, vp, C.c_long, C.c_int, C.c_int]
         L.vo_deconvolve_avx2_u8.argtypes = [C.c_uint, vp, vp]
@@ -118,6 +119,15 @@ def deconvolve_u32(framebits, sym_u32, ge=False):
     rc = lib().vo_deconvolve_opt(framebits, _p(sym_u32), _p(out), 1 if ge else 0)
     assert rc == 0
     return out
+
+
+def trace_state0(framebits, sym_u8, ge=False):
+    """metric of state 0 after every trellis step (after the renormalisation where there is one): framebits+6 values"""
+    sym_u8 = np.ascontiguousarray(sym_u8, np.uint8)
+    assert sym_u8.size == sym_len(framebits)
+    tr = np.zeros(framebits + 6, np.uint8)
+    assert lib().vo_trace_state0_u8(framebits, _p(sym_u8), 1 if ge else 0, _p(tr)) == 0
+    return tr
 
 
 def decode_batch(framebits, sym_u8, nthreads=1, avx2=False, ge=False):

@@ -82,8 +82,16 @@ static void vo_chainback(unsigned framebits, const uint64_t *dec,
     }
 }
 
+static int vo_decode_core_t(unsigned framebits, const uint32_t *s32,
+                            const uint8_t *s8, unsigned char *out, int ge, uint8_t *trace0);
 static int vo_decode_core(unsigned framebits, const uint32_t *s32,
                           const uint8_t *s8, unsigned char *out, int ge) {
+    return vo_decode_core_t(framebits, s32, s8, out, ge, NULL);
+}
+/* trace0 (optional, framebits+6 entries): the metric of state 0 after every trellis step, after the renormalisation
+ * where there is one - what tests/test_oracle_kat.py checks against a hand-derived trajectory */
+static int vo_decode_core_t(unsigned framebits, const uint32_t *s32,
+                            const uint8_t *s8, unsigned char *out, int ge, uint8_t *trace0) {
     if (framebits > VO_MAXBITS) return 1;
     vo_init_masks();
     uint64_t dec[VO_MAXBITS + 6]; /* deconvolve.cpp:93,127: on the stack */
@@ -98,12 +106,15 @@ static int vo_decode_core(unsigned framebits, const uint32_t *s32,
         for (int half = 0; half < 2; half++, t++) {
             for (int j = 0; j < 4; j++)
                 sy[j] = s32 ? (uint8_t)(s32[4 * t + j] & 0xFF) : s8[4 * t + j];
-            if (half == 0)
+            if (half == 0) {
                 dec[t] = vo_step(sy, a, b);
-            else
+                if (trace0) trace0[t] = b[0];
+            } else {
                 dec[t] = vo_step(sy, b, a);
+            }
         }
         vo_renorm(a, ge);
+        if (trace0) trace0[t - 1] = a[0];
     }
     vo_chainback(framebits, dec, out);
     return 0;
@@ -126,6 +137,11 @@ int vo_deconvolve_u8(unsigned framebits, const uint8_t *symbols,
 int vo_deconvolve_u8_ge(unsigned framebits, const uint8_t *symbols,
                         unsigned char *out) {
     return vo_decode_core(framebits, NULL, symbols, out, 1);
+}
+
+int vo_trace_state0_u8(unsigned framebits, const uint8_t *symbols, int ge, uint8_t *trace0) {
+    unsigned char out[(VO_MAXBITS + 7) / 8];
+    return vo_decode_core_t(framebits, NULL, symbols, out, ge, trace0);
 }
 
 /* ---- batch drivers --------------------------------------------------------- */

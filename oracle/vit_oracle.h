@@ -43,6 +43,9 @@ int vo_deconvolve_u8(unsigned framebits, const uint8_t *symbols,
 /* Same with the MASM twins' `>=150` renormalise test (decon_avx2.asm:97,114). */
 int vo_deconvolve_u8_ge(unsigned framebits, const uint8_t *symbols,
                         unsigned char *out);
+/* Test hook: the metric of state 0 after every trellis step (framebits+6 entries; after the renormalisation on the
+ * steps that have one), for a KAT whose trajectory is derived by hand (tests/test_oracle_kat.py). */
+int vo_trace_state0_u8(unsigned framebits, const uint8_t *symbols, int ge, uint8_t *trace0);
 /* Batch helpers (frames contiguous; u8 symbols, 4*(framebits+6) per frame;
  * (framebits+7)/8 output bytes per frame).  nthreads<=1 -> serial. */
 int vo_decode_batch_u8(unsigned framebits, const uint8_t *symbols,

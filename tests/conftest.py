@@ -28,6 +28,10 @@ def V():
     mod = _vitpkg.load_package()
     if not os.path.exists(mod.LIB_PATH):
         mod.build()
+    # The library's default comparator is the MASM decoders' `>= 150` (what an installed viterbi.dll runs; asserted in
+    # tests/test_abi.py).  The oracle's default, and what most tests compare with, is the C decoders' `> 150`: the
+    # session runs in that mode, and the tests of the comparator select each mode explicitly.
+    mod.set_renorm_ge(0)
     return mod
 
 

@@ -106,3 +106,14 @@ def test_ingest_stage_environment_knobs():
     ncpu = len(os.sched_getaffinity(0))
     m = re.search(r"RESULT 50 1 4 5 16 1 (\d+) 7 0", out)
     assert m and 0 <= int(m.group(1)) <= ncpu // 4  # a quarter of: affinity mask, capped by a cgroup CPU quota
+
+
+def test_default_renormalise_comparator_is_the_shipped_dll_s():
+    """a fresh process: the comparator defaults to `>= 150` (the reference's MASM decoders, configuration Rel_asm, which
+    its README tells users to build - what an installed viterbi.dll runs); VITERBI_AMD_RENORM_GE=0 selects the C decoders"""
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import _vitpkg; V = _vitpkg.load_package();"
+            "print('RESULT', V.set_renorm_ge(0), V.set_renorm_ge(1), V.set_renorm_ge(1))" % ROOT)
+    clean = {k: v for k, v in os.environ.items() if k != "VITERBI_AMD_RENORM_GE"}
+    assert "RESULT 1 0 1" in subprocess.check_output([sys.executable, "-c", code], env=clean, text=True)
+    assert "RESULT 0 0 1" in subprocess.check_output([sys.executable, "-c", code], env=dict(clean, VITERBI_AMD_RENORM_GE="0"), text=True)

@@ -136,7 +136,7 @@ def test_renorm_ge_mode(V, O, torch_cuda, kernel, framebits, n):
     want_gt = O.decode_batch(framebits, sym, nthreads=8)
     want_ge = O.decode_batch(framebits, sym, nthreads=8, ge=True)
     assert (want_gt != want_ge).any(axis=1).sum() >= 3, "the frame set does not separate the two comparators"
-    assert V.set_renorm_ge(0) == 0  # the default
+    assert V.set_renorm_ge(0) == 0  # the test session's mode (conftest.py)
     assert np.array_equal(_gpu_decode(V, torch_cuda, sym, framebits, kernel), want_gt)
     V.set_renorm_ge(1)
     try:

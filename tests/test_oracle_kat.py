@@ -276,3 +276,28 @@ def test_rs_syndromes_from_generator_remainder():
             S2.append(v)
         assert S == S2
         assert (trial % 2 == 1) or (r == [0] * 10 and S == [0] * 10)
+
+
+def test_renormalise_comparators_on_a_hand_derived_trajectory(O):
+    """Pins the oracle's TWO renormalise comparators by a trajectory derived by hand from the source lines, not by the
+    oracle's own code (round-3 advisor).  Input: every soft symbol = 100 (a weak "0" on all four outputs).
+
+    * Branch metric (deconvolve.cpp:335-351): x_j = 100 or 155 (= 100 ^ 0xFF); the all-zero branch has x = (100,100,100,100),
+      metric = avg(avg(100,100),avg(100,100)) >> 2 = 25; any other class holds at least one 155, so metric >= 25, and
+      since metric <= 155 >> 2 = 38 also 63 - metric >= 25: EVERY branch costs at least 25.
+    * So after t+1 steps every state's metric is >= 25 (t+1) minus the uniform renormalisations (initial metrics are
+      0 and 63, const.asm:19-25), and the all-zero path (state 0 -> state 0, butterfly 0: new[0] = min(old[0] + 25,
+      old[32] + 38)) attains it: m0(t) = 25 (t+1) - 63 r(t), r = renormalisations so far.  No clamp interferes: m0 + 25
+      <= 225 < 255, and a renormalisation happens at m0 >= 150 > 63 with every other metric >= m0.
+    * Renormalise256 runs after the odd steps t = 1, 3, 5, ... (deconvolve.cpp:398-412).  m0 = 50, 100, then EXACTLY 150
+      at t = 5: `> 150` (C decoders, deconvolve.cpp:408) does not subtract, `>= 150` (MASM decoders,
+      decon_avx2.asm:97,114 `cmp sil,150 ; jb`) does.  From t = 9 on the two trajectories coincide again."""
+    fb = 18  # 24 trellis steps
+    sym = np.full(O.sym_len(fb), 100, np.uint8)
+    want_gt = [25, 50, 75, 100, 125, 150, 175, 200 - 63, 162, 187 - 63, 149, 174 - 63, 136, 161 - 63, 123, 148, 173, 198 - 63]
+    want_ge = [25, 50, 75, 100, 125, 150 - 63, 112, 137, 162, 187 - 63, 149, 174 - 63, 136, 161 - 63, 123, 148, 173, 198 - 63]
+    assert O.trace_state0(fb, sym, ge=False)[:18].tolist() == want_gt
+    assert O.trace_state0(fb, sym, ge=True)[:18].tolist() == want_ge
+    assert want_gt[5:9] != want_ge[5:9] and want_gt[9:] == want_ge[9:]
+    # the decoded bits are the all-zero message in both modes (the uniform shift is invisible without a clamp)
+    assert not O.decode_batch(fb, sym[None, :]).any() and not O.decode_batch(fb, sym[None, :], ge=True).any()

@@ -74,12 +74,15 @@ int g_cus = 0;
 char g_init_err[160] = "no usable gfx950 (MI355X) HIP device; libviterbi has no CPU path";
 std::atomic<int> g_fault{0};   // reference: exceptCounter / decon_savemode
 std::atomic<int> g_kernel{0};  // 0 auto, 1 wave, 2 packed, 3 latency
-// Renormalisation comparator of every decoder kernel: 0 = `> 150` (the reference's C decoders, deconvolve.cpp:399,408,
-// configuration Rel_cpp), 1 = `>= 150` (its MASM decoders, decon_avx2.asm:97,114 `cmp sil,150 ; jb mainloop`,
-// configuration Rel_asm).  Environment VITERBI_AMD_RENORM_GE=1 sets the start-up value; vit_set_renorm_ge() changes it.
+// Renormalisation comparator of every decoder kernel: 1 = `>= 150`, the reference's MASM decoders (decon_avx2.asm:97,114
+// `cmp sil,150 ; jb mainloop`; configuration Rel_asm - the one the reference's README tells users to build (README.md:50-52),
+// i.e. what an installed viterbi.dll runs, and therefore the DEFAULT of this drop-in since round 4); 0 = `> 150`, its C
+// decoders (deconvolve.cpp:399,408, configuration Rel_cpp - the one that can be compiled outside Windows and that the
+// timed AVX2 port and bench.py's parity check implement).  Environment VITERBI_AMD_RENORM_GE=0/1 sets the start-up value;
+// vit_set_renorm_ge() changes it.
 std::atomic<int> g_renorm_ge{[] {
     const char* e = getenv("VITERBI_AMD_RENORM_GE");
-    return e && atoi(e) != 0 ? 1 : 0;
+    return e ? (atoi(e) != 0 ? 1 : 0) : 1;
 }()};
 // what an exported entry point reads ONCE per call
 struct DecodeMode {

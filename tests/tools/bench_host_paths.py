@@ -5,6 +5,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import _vitpkg
 V = _vitpkg.load_package(); O = _vitpkg.load_oracle(); V.initialize(); V.WakeUpYMM()
+V.set_renorm_ge(0)  # the oracle's default comparator (`> 150`, the C decoders); the library's default is the MASM decoders' `>= 150`
 fb = 768
 sym = O.noisy_frames(1, fb, seed=1)[0].astype(np.uint32)
 out = np.zeros(fb // 8, np.uint8)

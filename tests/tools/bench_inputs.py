@@ -17,6 +17,7 @@ import _vitpkg  # noqa: E402
 from bench import make_frames  # noqa: E402
 
 V = _vitpkg.load_package()
+V.set_renorm_ge(0)  # the oracle's default comparator (`> 150`, the C decoders); the library's default is the MASM decoders' `>= 150`
 O = _vitpkg.load_oracle()
 dev = torch.device("cuda", 0)
 V.initialize()

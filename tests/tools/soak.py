@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 import _vitpkg
 from bench import make_frames
 V = _vitpkg.load_package(); O = _vitpkg.load_oracle(); V.initialize()
+V.set_renorm_ge(0)  # the oracle's default comparator (`> 150`, the C decoders); the library's default is the MASM decoders' `>= 150`
 dev = torch.device("cuda", 0)
 ncpu = len(os.sched_getaffinity(0))
 total = bad = 0

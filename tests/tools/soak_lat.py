@@ -7,6 +7,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import _vitpkg
 V = _vitpkg.load_package(); O = _vitpkg.load_oracle(); V.initialize()
+V.set_renorm_ge(0)  # the oracle's default comparator (`> 150`, the C decoders); the library's default is the MASM decoders' `>= 150`
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 t0 = time.time(); frames = 0; bad = 0; cases = 0
 

@@ -10,6 +10,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import _vitpkg
 V = _vitpkg.load_package(); O = _vitpkg.load_oracle(); V.initialize()
+V.set_renorm_ge(0)  # the oracle's default comparator (`> 150`, the C decoders); the library's default is the MASM decoders' `>= 150`
 ntab = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 dev = torch.device("cuda", 0)
 total = bad = 0

@@ -6,8 +6,8 @@ OUT=$R/gpurun_out/pk_pmc; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 for v in "$@"; do
   name=${v%%=*}; kv=${v#*=}
   export "$kv"
-  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/a_$name -- python3 $R/bench.py --no-cpu --no-pipelined --no-rs --steps 3 --warmup 1 $PK_PMC_ARGS > $OUT/a_$name.log 2>&1
-  rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/b_$name -- python3 $R/bench.py --no-cpu --no-pipelined --no-rs --steps 3 --warmup 1 $PK_PMC_ARGS > $OUT/b_$name.log 2>&1
+  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/a_$name -- python3 $R/bench.py --no-cpu --no-pipelined --no-rs --no-sensitivity --steps 3 --warmup 1 $PK_PMC_ARGS > $OUT/a_$name.log 2>&1
+  rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/b_$name -- python3 $R/bench.py --no-cpu --no-pipelined --no-rs --no-sensitivity --steps 3 --warmup 1 $PK_PMC_ARGS > $OUT/b_$name.log 2>&1
   unset "${kv%%=*}"
   python3 - $OUT $name <<'PY'
 import csv, glob, sys, collections

@@ -739,6 +739,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
 #pragma unroll
         for (int k = 0; k < 4; k++) sel[k] = hb | (0x00040000u + 0x00010001u * k);  // byte k of half 0 / half 1
     }
+    const PrepassLane PL = prepass_lane(lane);
     u32 A = l5 == 0 ? 0u : 0x003F003Fu, B = 0x003F003Fu;  // const.asm:19-25 (0-based, step 0 is even)
     u32 acc0 = 0, acc1 = 0;
     v32u r0, r1;  // register-resident decisions of blocks [0,R)
@@ -758,7 +759,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
             }
             if ((rb & 1u) == 0) {
                 __syncthreads();  // every lane is done with the previous table
-                prepass(pack_step(sa), pack_step(sb), tab, lane, sel);
+                prepass(pack_step(sa), pack_step(sb), tab, PL, sel);
                 const u32 tn = (rb + 2u) * 16u + tau;
                 sa = load_step<SYM32>(a_sym, tn, tn < a_T);  // prefetch the next 32 steps' symbols
                 sb = load_step<SYM32>(b_sym, tn, tn < b_T);
@@ -955,6 +956,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
 #pragma unroll
         for (int k = 0; k < 4; k++) sel[k] = hb | (0x00040000u + 0x00010001u * k);
     }
+    const PrepassLane PL = prepass_lane(lane);
 
 #ifndef VIT_LONG_FIRST_STATIC
 #define VIT_LONG_FIRST_STATIC 1
@@ -1068,7 +1070,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
 #endif
                 if ((rb & 1u) == 0) {
                     __syncthreads();
-                    prepass(pack_step(sa), pack_step(sb), tab, lane, sel);
+                    prepass(pack_step(sa), pack_step(sb), tab, PL, sel);
                     const u32 tn = (rb + 2u) * 16u + tau;
                     sa = load_step<SYM32>(a_sym, tn, tn < a_T);
                     sb = load_step<SYM32>(b_sym, tn, tn < b_T);

@@ -598,6 +598,7 @@ __global__ __launch_bounds__(64, 2) void vit_pk8_kernel(const uint8_t* __restric
 #pragma unroll
         for (int k = 0; k < 4; k++) sel[k] = hb | (0x00040000u + 0x00010001u * k);
     }
+    const PrepassLane PL = prepass_lane(lane);
     u32 N[2][2] = {{l4 == 0 ? 0u : 0x003F003Fu, 0x003F003Fu}, {0x003F003Fu, 0x003F003Fu}};  // const.asm:19-25 (0-based, step 0 is even)
     u32 acc[2][2] = {{0u, 0u}, {0u, 0u}};
     v32u r00, r01, r10, r11;  // register-resident decisions of blocks [0,R)
@@ -608,7 +609,7 @@ __global__ __launch_bounds__(64, 2) void vit_pk8_kernel(const uint8_t* __restric
         u32 v = 0;
         for (u32 rb = 0; rb < nb; rb++) {
             __syncthreads();  // every lane is done with the previous table
-            prepass(pack_step(sa), pack_step(sb), tab, lane, sel);
+            prepass(pack_step(sa), pack_step(sb), tab, PL, sel);
             const u32 tn = (rb + 1u) * 16u + tau;
             sa = load_step<SYM32>(a_sym, tn, tn < a_T);  // prefetch the next 16 steps' symbols
             sb = load_step<SYM32>(b_sym, tn, tn < b_T);

@@ -553,7 +553,15 @@ struct Tb16Run {
     }
 };
 // One part [lo, lo + 16*nl) of four equally long frames; decisions of block b at dec + (b - slot0)*512.  Returns P after step lo.
-DEV u32 traceback_part16(const char* dec, u32* img, u32 fstride, u32 lane, u32 lo, u32 nl, u32 slot0, u32 P_top, u32 dmask) {
+// SPEC (round 4, the long-frame kernel's in-flight parts): the position at the part's top is not known yet.  Every lane - the
+// two top ones too - then starts 30 steps above its block from state 0 (the three history blocks above the part must be in LDS),
+// the top lane is trusted, and *p_spec receives the position it passed through at the part's top: the part's output is final iff
+// that equals what the part above ends in, which the caller checks once the frame's last part has been traced from the true end
+// state.  *misses = speculative blocks of the wave that missed in the first pass.  TOMEM (gout = per lane: its frame's output):
+// the lane's 16 decoded bits go straight to memory as two MSB-first bytes (deconvolve.cpp:432-433) instead of into the LDS image.
+template <bool SPEC = false, bool TOMEM = false>
+DEV u32 traceback_part16(const char* dec, u32* img, u32 fstride, u32 lane, u32 lo, u32 nl, u32 slot0, u32 P_top, u32 dmask,
+                         uint8_t* gout = nullptr, u32* p_spec = nullptr, u32* misses = nullptr) {
 #ifdef VIT_DIAG_NO_TB
     return P_top;
 #endif
@@ -561,7 +569,7 @@ DEV u32 traceback_part16(const char* dec, u32* img, u32 fstride, u32 lane, u32 l
     const u32 fi = lane >> 4, q = lane & 15u;
     const u32 tbase = lo + q * 16u;
     const bool has_work = q < nl;
-    const u32 above = nl - q;  // blocks from this one up to the top of the part (has_work: >= 1)
+    const u32 above = SPEC ? 3u : nl - q;  // blocks from this one up to the top of the part (has_work: >= 1)
     const bool fixed = has_work && above <= 2u;  // its warm-up would cross the part's top: it starts there, from the true position
     const u32 C = (fi >> 1) * 256u + (fi & 1u) * 2u;
     const u32 dbase = (u32)(uintptr_t)(const __attribute__((address_space(3))) char*)dec;
@@ -591,9 +599,15 @@ DEV u32 traceback_part16(const char* dec, u32* img, u32 fstride, u32 lane, u32 l
     for (int pass = 0; pass < 17; pass++) {
         // the block above = the next lane of the same 16-lane row: one DPP move (row_shl:1), no LDS round trip in the pass loop
         const u32 nxt = (u32)__builtin_amdgcn_update_dpp(0, (int)P_out, 0x101, 0xF, 0xF, true);
-        const u32 new_in = (q + 1u < nl) ? nxt : PC_top;
+        const u32 new_in = (q + 1u < nl) ? nxt : (SPEC ? P_in : PC_top);
         const bool changed = has_work && !fixed && new_in != P_in;
-        if (!__any(changed)) break;
+        if constexpr (SPEC) {
+            const unsigned long long miss = __ballot(changed);
+            if (pass == 0) *misses = (u32)__popcll(miss);
+            if (miss == 0) break;
+        } else {
+            if (!__any(changed)) break;
+        }
         if (changed) {
             P_in = new_in;
             P = new_in | bbq;
@@ -605,8 +619,15 @@ DEV u32 traceback_part16(const char* dec, u32* img, u32 fstride, u32 lane, u32 l
     // decoded bit index of step t is t - 6 (a multiple of 16 here); decoded bit = NOT stored bit
     if (has_work) {
         const u32 h = (tbase - VIT_TAIL) >> 4;  // halfword index in the frame's bit image
-        reinterpret_cast<unsigned short*>(img + fi * fstride)[((h >> 1) & dmask) * 2u + (h & 1u)] = (unsigned short)~cur;
+        if constexpr (TOMEM) {
+            const u32 v = __builtin_bitreverse32(~cur & 0xFFFFu);  // byte 3 = bits 0..7 reversed, byte 2 = bits 8..15 reversed
+            gout[2u * h] = (uint8_t)(v >> 24);
+            gout[2u * h + 1u] = (uint8_t)(v >> 16);
+        } else {
+            reinterpret_cast<unsigned short*>(img + fi * fstride)[((h >> 1) & dmask) * 2u + (h & 1u)] = (unsigned short)~cur;
+        }
     }
+    if constexpr (SPEC) *p_spec = __shfl(P_in, (int)(fi * 16u + nl - 1u)) & 0xFCu;  // the top lane's position at the part's top
     return __shfl(P_out, (int)(fi * 16u)) & 0xFCu;
 }
 
@@ -886,18 +907,33 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
     }
 }
 
-// ---- frames longer than one segment: decisions beyond the last 17 blocks go through HBM ---------
-// (replaces the checkpoint + recompute scheme: one forward pass with history; HBM has >90 % headroom
-// on this VALU-bound path, so 8 B/step of spill each way is cheaper than 0.7 extra ACS passes.)
-// Blocks [0, G) of a wave's frames are written to its slice of `spill` (512 B per block, coalesced),
-// the last <= 17 blocks stay in LDS exactly as in the single-segment kernel.  The traceback walks
-// down from the LDS tail, then reloads 16 spilled blocks at a time into the same LDS region.
-// Workgroups are persistent: each takes the next group of 4 frames from an atomic counter, so the
-// spill buffer is sized by the resident waves, not by the batch, and a length-sorted descriptor
-// table is consumed longest-first.
-constexpr u32 LONG_LDS_BLOCKS = DUMP_GROUP + 1u;  // 17
+// ---- frames longer than one segment: decisions go through a 32-block register ring and, write-only, through HBM ---------
+// (history: round 1 checkpoint + recompute, 1.7x the ACS work; rounds 2-3 one forward pass whose blocks were spilled to HBM and
+// read back 16 at a time for a traceback after the forward pass: 8 B per frame-step each way.)
+// Round 4: the forward pass keeps the last 32 blocks of history in VGPRs (the ring the single-segment kernel uses) and writes every
+// block but the last 16 to the workgroup's slice of `spill` (512 B per block, coalesced) WITHOUT reading it back:
+//   * a group of four equally long frames of a multiple of 16 bits (every DAB size) is traced back IN FLIGHT.  Its frames are cut
+//     into parts of 256 steps from the top (part 0 = the frame's end); as soon as the ACS is two blocks past the top of part p >= 1,
+//     at the next point where the branch-metric table is dead (so that 19 blocks fit the workgroup's 10 KB of LDS), the part's 17
+//     blocks and the two above go from the ring to LDS and the part is traced speculatively (traceback_part16<SPEC>: every lane 30
+//     steps above its block from state 0, the top lane trusted), its decoded bits go straight to `out`, and the position at its top
+//     (spec) and at its bottom (out) are recorded - lane p of two registers holds part p, four frames x 8 bits.
+//   * after the forward pass part 0 is traced from the true end state (state 0), and the chain is checked from the top down:
+//     part p is final iff spec(p) = out(p - 1).  The first part that fails - 0.35 % of the frame-parts at Eb/N0 = 3 dB
+//     (profiles/r03_merge_depth.txt) - is reloaded from the spill (17 blocks), traced from its true top and checked again:
+//     the fixed point is the serial ChainBack (deconvolve.cpp:416-435), as before.
+//   * a wave whose first in-flight part shows >= TB_HARD_MISSES missed blocks (input without signal: half of all 30-step
+//     speculations fail) stops tracing in flight: its parts stay marked "unchecked" and the top-down loop traces them all from
+//     the spill - the behaviour of rounds 2-3.
+//   * other groups (mixed lengths in a wave, lengths that are not a multiple of 16) take the general traceback form after the
+//     forward pass, last 17 blocks from the ring, the others read back from the spill as before.
+// Workgroups are persistent: each takes the next group of 4 frames from an atomic counter, so the spill buffer is sized by the
+// resident waves, not by the batch, and a length-sorted descriptor table is consumed longest-first.
+constexpr u32 LONG_LDS_BLOCKS = DUMP_GROUP + 1u;  // 17: the blocks of one 256-step part
+constexpr u32 LONG_KEEP = DUMP_GROUP;             // the last 16 blocks of a frame are never spilled
+constexpr u32 SPEC_BLOCKS = LONG_LDS_BLOCKS + 2u; // an in-flight part and the two blocks above it (30-step warm-up of its top lane)
 
-constexpr u32 IMG_RING = 16;  // output bit image of the long-frame kernel: a ring of 16 words (512 bits) per frame
+constexpr u32 IMG_RING = 16;  // output bit image of the general form: a ring of 16 words (512 bits) per frame
 
 __host__ __device__ inline PkLayout pk_layout_long(u32 maxfb) {
     PkLayout l;
@@ -910,6 +946,85 @@ __host__ __device__ inline PkLayout pk_layout_long(u32 maxfb) {
     l.total = l.dec_bytes + tabregion;  // 10 KB for every length: 16 waves per CU
     return l;
 }
+static_assert(SPEC_BLOCKS * DEC_BLOCK <= DUMP_GROUP * DEC_BLOCK + (u32)TAB_BYTES, "an in-flight part must fit dec + the dead table");
+
+// Where the forward pass keeps the history it may still need (besides the write-only spill): a WINDOW whose slot 0 holds block
+// `base` (a signed block number: the short bottom part of a frame starts "below block 0").  Block base + d goes to LDS slot d for
+// d < 16 (the dec region); d = 16 .. 19 would land on the branch-metric table, which is live, so those four blocks wait in eight
+// VGPRs (the carry) and reach LDS slots 16 .. 19 only when the table is dead: for an in-flight part (slots 0 .. 18 = its 17 blocks and
+// the two above), or after the forward pass (slot 16 = the frame's last block).  After an in-flight part the window moves up 16
+// blocks and the carried blocks become its slots 0 .. 3.
+// The carry is four register pairs, written by ONE inline-asm statement with scalar branches inside: to the compiler a single
+// instruction that updates eight registers in place.  Every plainer form cost more than the whole scheme is worth
+// (profiles/r04_ab_long_inflight.txt): a switch over the elements of an array or struct - the optimiser merges the four stores into one
+// with a computed index and the object lives in scratch memory, i.e. a scratch load behind `s_waitcnt vmcnt(0)` (= behind the
+// acknowledgement of the spill stores just issued) at every part, +14 % on a multi-round launch; four separate locals - a web of phi
+// copies, eight v_mov_b64 in EVERY block, +3 %; an 8-dword vector with a dynamic index - 16 to 24 v_cndmask per block.
+struct Carry {
+    u32 a0, b0, a1, b1, a2, b2, a3, b3;  // (acc1, acc0) of window positions 16, 17, 18, 19
+};
+DEV void carry_put(Carry& c, int d, u32 x, u32 y) {  // d wave-uniform; positions below 16 leave the carry alone
+    asm volatile(
+        "s_cmp_lt_i32 %[d], 16\n\t"
+        "s_cbranch_scc1 .Lcy_end%=\n\t"
+        "s_cmp_lg_u32 %[d], 16\n\t"
+        "s_cbranch_scc1 .Lcy_1%=\n\t"
+        "v_mov_b32 %[a0], %[x]\n\t"
+        "v_mov_b32 %[b0], %[y]\n\t"
+        "s_branch .Lcy_end%=\n"
+        ".Lcy_1%=:\n\t"
+        "s_cmp_lg_u32 %[d], 17\n\t"
+        "s_cbranch_scc1 .Lcy_2%=\n\t"
+        "v_mov_b32 %[a1], %[x]\n\t"
+        "v_mov_b32 %[b1], %[y]\n\t"
+        "s_branch .Lcy_end%=\n"
+        ".Lcy_2%=:\n\t"
+        "s_cmp_lg_u32 %[d], 18\n\t"
+        "s_cbranch_scc1 .Lcy_3%=\n\t"
+        "v_mov_b32 %[a2], %[x]\n\t"
+        "v_mov_b32 %[b2], %[y]\n\t"
+        "s_branch .Lcy_end%=\n"
+        ".Lcy_3%=:\n\t"
+        "v_mov_b32 %[a3], %[x]\n\t"
+        "v_mov_b32 %[b3], %[y]\n"
+        ".Lcy_end%=:"
+        : [a0] "+v"(c.a0), [b0] "+v"(c.b0), [a1] "+v"(c.a1), [b1] "+v"(c.b1), [a2] "+v"(c.a2), [b2] "+v"(c.b2), [a3] "+v"(c.a3), [b3] "+v"(c.b3)
+        : [d] "s"(d), [x] "v"(x), [y] "v"(y)
+        : "scc");
+}
+// carried blocks 0 .. n - 1 -> LDS slots first .. first + n - 1
+DEV void carry_to_lds(const Carry& c, char* dec, u32 dslot, u32 first, u32 n) {
+    if (n > 0u) *reinterpret_cast<uint2*>(dec + (first + 0u) * DEC_BLOCK + dslot) = make_uint2(c.a0, c.b0);
+    if (n > 1u) *reinterpret_cast<uint2*>(dec + (first + 1u) * DEC_BLOCK + dslot) = make_uint2(c.a1, c.b1);
+    if (n > 2u) *reinterpret_cast<uint2*>(dec + (first + 2u) * DEC_BLOCK + dslot) = make_uint2(c.a2, c.b2);
+    if (n > 3u) *reinterpret_cast<uint2*>(dec + (first + 3u) * DEC_BLOCK + dslot) = make_uint2(c.a3, c.b3);
+}
+// four per-frame positions (uniform within each 16-lane row) as one word, frame k in byte k
+DEV u32 pack_rows(u32 P) {
+    return (u32)__builtin_amdgcn_readlane((int)P, 0) | ((u32)__builtin_amdgcn_readlane((int)P, 16) << 8) |
+           ((u32)__builtin_amdgcn_readlane((int)P, 32) << 16) | ((u32)__builtin_amdgcn_readlane((int)P, 48) << 24);
+}
+
+#ifdef VIT_DIAG_SPEC  /* test build: what the fast groups did - [0] groups, [1] parts traced in flight, [2] groups that gave up tracing in
+                        flight (input without signal), [3] parts traced after the forward pass beyond part 0, [4] of those: parts that had
+                        been traced in flight and failed their check */
+__device__ unsigned long long g_diag_spec[8];
+#define SPEC_COUNT(i) do { if (lane == 0) atomicAdd(&g_diag_spec[i], 1ull); } while (0)
+#else
+#define SPEC_COUNT(i) do { } while (0)
+#endif
+#ifndef VIT_LONG_BASE_PRIO
+#define VIT_LONG_BASE_PRIO 1
+#endif
+#ifndef VIT_LONG_INFLIGHT
+#define VIT_LONG_INFLIGHT 1  /* 0: no in-flight parts - every part is traced after the forward pass from the spill (A/B; the rounds 2-3 traffic) */
+#endif
+
+// The workgroups of these kernels are ONE wavefront, and a wavefront's LDS instructions execute in issue order: what a
+// __syncthreads() has to provide here is only that the compiler keeps LDS accesses on their side of it.  __syncthreads() itself
+// is a workgroup-scope fence, i.e. `s_waitcnt vmcnt(0)` as well - in the long-frame kernel that is a wait for the acknowledgement
+// of the spill and output stores just issued (1-2 us each time, 4.5 us per in-flight part: profiles/r04_ab_long_inflight.txt).
+DEV void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 template <bool SYM32>
 __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __restrict__ sym, uint8_t* __restrict__ out,
@@ -919,7 +1034,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
                                                              u32 ngroups, u32 short_max,
                                                              const unsigned* __restrict__ split_gate, u32 renorm_c) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    char* dec = lds;                  // 16 blocks; the 17th (last) lands on the dead table
+    char* dec = lds;                  // 16 blocks; 17th ... 20th land on the table when it is dead
     char* tab = lds + lay.dec_bytes;  // [tau][pair][c] -> M; after the ACS: last block, scratch, image
     u32* img = reinterpret_cast<u32*>(lds + lay.img_off);
     const u32 lane = threadIdx.x;
@@ -971,9 +1086,6 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         prio_slot = hwid & 3u;  // wave slot within the SIMD
     }
-#ifndef VIT_LONG_BASE_PRIO
-#define VIT_LONG_BASE_PRIO 1
-#endif
 #if VIT_LONG_BASE_PRIO
     // every wave of this kernel at the level of the single-segment kernel's three regular waves: when a split table runs both kernels
     // side by side, the few long groups are the critical path and must not rank below the other kernel's waves
@@ -1008,6 +1120,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
         if (grp >= ngroups) break;
 #ifdef VIT_DIAG_TIMES
         const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long diag_tr = 0;  // time spent in in-flight parts
 #endif
         const long long f0 = (long long)grp * 4;
         u32 fbits[4];
@@ -1043,23 +1156,39 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
             continue;
         }
         const u32 nblk = (maxfb + VIT_TAIL + 15u) >> 4;
-        const u32 G = nblk > LONG_LDS_BLOCKS ? nblk - LONG_LDS_BLOCKS : 0u;  // spilled blocks (<= spill_blocks)
+        const u32 G = nblk > LONG_KEEP ? nblk - LONG_KEEP : 0u;  // spilled blocks (<= spill_blocks)
         const u32 T_max = maxfb + VIT_TAIL;
         const u32 a_fb = pp ? fbits[2] : fbits[0], b_fb = pp ? fbits[3] : fbits[1];
         const u32 a_T = a_fb ? a_fb + VIT_TAIL : 0u, b_T = b_fb ? b_fb + VIT_TAIL : 0u;
         constexpr size_t SB = SYM32 ? 4 : 1;  // bytes per soft symbol in memory
         const uint8_t* a_sym = sym + SB * (pp ? soff[2] : soff[0]);
         const uint8_t* b_sym = sym + SB * (pp ? soff[3] : soff[1]);
+        const u32 fi = lane >> 4;
+        const u32 t_fb = fi == 0 ? fbits[0] : fi == 1 ? fbits[1] : fi == 2 ? fbits[2] : fbits[3];
+        uint8_t* o_f = out + (fi == 0 ? ooff[0] : fi == 1 ? ooff[1] : fi == 2 ? ooff[2] : ooff[3]);
+#if VIT_TB16
+        const bool fast = fbits[0] == fbits[1] && fbits[1] == fbits[2] && fbits[2] == fbits[3] && (maxfb & 15u) == 0;
+#else
+        const bool fast = false;
+#endif
+        // parts of a fast group: part p = steps [max(hi - 256, 6), hi), hi = T_max - 256 p; its top block is nblk - 1 - 16 p and its
+        // window base nblk - 17 - 16 p (part 0 = the frame's last 17 blocks)
+        const u32 NP = fast ? (maxfb + 255u) >> 8 : 0u;
+        u32 p_next = (VIT_LONG_INFLIGHT && NP > 1u) ? NP - 1u : 0u;  // bottom part first; 0 = nothing (left) to trace in flight
+        // the window the ACS is filling: the next in-flight part's, else the frame's last 17 blocks (all of a shorter frame)
+        int base = (fast ? (int)nblk - (int)LONG_LDS_BLOCKS : (int)(nblk > LONG_LDS_BLOCKS ? nblk - LONG_LDS_BLOCKS : 0u)) - 16 * (int)p_next;
+        u32 rec_spec = 0xFFFFFFFFu, rec_out = 0u;  // lane p: part p, frame k in byte k; 0xFFFFFFFF = not traced (never equals a position)
 
         // ---- forward pass: ACS with history over all blocks ----
         u32 A = l5 == 0 ? 0u : 0x003F003Fu, B = 0x003F003Fu;
         u32 acc0 = 0, acc1 = 0;
+        Carry cy = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
         {
             auto sa = load_step<SYM32>(a_sym, tau, tau < a_T), sb = load_step<SYM32>(b_sym, tau, tau < b_T);
             u32 v = 0;
             for (u32 rb = 0; rb < nblk; rb++) {
 #if VIT_LONG_ROT
-                if (VIT_LONG_ROT == 2 ? ngroups <= gridDim.x : grp + gridDim.x >= ngroups) {
+                if (VIT_LONG_ROT == 3 ? true : VIT_LONG_ROT == 2 ? ngroups <= gridDim.x : grp + gridDim.x >= ngroups) {
                     switch ((prio_slot + rb) & 3u) {
                         case 0: __builtin_amdgcn_s_setprio(0); break;
                         case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -1069,12 +1198,12 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
                 }
 #endif
                 if ((rb & 1u) == 0) {
-                    __syncthreads();
+                    wave_sync();
                     prepass(pack_step(sa), pack_step(sb), tab, PL, sel);
                     const u32 tn = (rb + 2u) * 16u + tau;
                     sa = load_step<SYM32>(a_sym, tn, tn < a_T);
                     sb = load_step<SYM32>(b_sym, tn, tn < b_T);
-                    __syncthreads();
+                    wave_sync();
                 }
 #if VIT_TAB_STATIC
                 if (VIT_STEPS6 && rb + 1u == nblk && (T_max & 15u) == 6u) {
@@ -1090,26 +1219,130 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
                 else
                     steps16<true>(v, A, B, acc0, acc1, tab + (rb & 1u) * 1024u, L, lane, C);
 #endif
-                if (rb < G) {
-                    wspill[(size_t)rb * 64u] = make_uint2(acc1, acc0);  // the order of the LDS blocks: a reload is a plain copy
-                } else {
-                    if (rb + 1u == nblk) __syncthreads();  // the last block lands on the table: all reads done first
-                    *reinterpret_cast<uint2*>(dec + (rb - G) * DEC_BLOCK + dslot) = make_uint2(acc1, acc0);
+                const uint2 hw = make_uint2(acc1, acc0);  // the order of the LDS blocks: a reload is a plain copy
+                if (rb < G) wspill[(size_t)rb * 64u] = hw;
+                const int d = (int)rb - base;  // position in the window (< 0: a block no later part of this wave needs in LDS)
+                if (d >= 0 && d < (int)DUMP_GROUP) *reinterpret_cast<uint2*>(dec + (u32)d * DEC_BLOCK + dslot) = hw;
+                carry_put(cy, d, acc1, acc0);
+                // part p_next is traced in flight after the first ODD block (the table is dead then) that is >= two blocks above its top
+                if (p_next && d >= (int)LONG_LDS_BLOCKS + 1 && (rb & 1u)) {
+                    const u32 hi = T_max - 256u * p_next;
+                    const u32 lo = hi > 256u + VIT_TAIL ? hi - 256u : VIT_TAIL;
+                    const u32 nc = (u32)d - (DUMP_GROUP - 1u);  // carried blocks: 3 or 4
+#ifndef VIT_LONG_TRACE_PRIO
+#define VIT_LONG_TRACE_PRIO (-1)  /* issue priority of an in-flight part, -1 = leave it alone.  A part is a chain of ~50 dependent LDS reads with
+                                     five instructions each; raising its priority (3) so that none of them queues behind the other waves' ACS
+                                     measured 2-10 % SLOWER on multi-round launches, lowering it (0) no better: profiles/r04_ab_long_inflight.txt */
+#endif
+                    if (VIT_LONG_TRACE_PRIO >= 0) __builtin_amdgcn_s_setprio(VIT_LONG_TRACE_PRIO >= 0 ? VIT_LONG_TRACE_PRIO : 0);
+#ifdef VIT_DIAG_TIMES
+                    const unsigned long long diag_ta = __builtin_amdgcn_s_memrealtime();
+#endif
+                    wave_sync();  // every table read of this block is done
+                    carry_to_lds(cy, dec, dslot, DUMP_GROUP, nc);
+                    wave_sync();
+                    u32 pspec = 0, misses = 0;
+                    const u32 pout = traceback_part16<true, true>(dec, nullptr, 0u, lane, lo, (hi - lo) >> 4, (u32)base, 0u, 0u, o_f, &pspec, &misses);
+#ifdef VIT_SPEC_SABOTAGE  /* test build: every in-flight part fails its check and comes back from the spill (outputs must not change) */
+                    const u32 ks = pack_rows(pspec) ^ ((p_next & 1u) ? 0x04040404u : 0x00000800u), ko = pack_rows(pout);
+#else
+                    const u32 ks = pack_rows(pspec), ko = pack_rows(pout);
+#endif
+                    if (lane == p_next) {
+                        rec_spec = ks;
+                        rec_out = ko;
+                    }
+                    SPEC_COUNT(1);
+                    if (misses >= TB_HARD_MISSES && p_next > 1u) SPEC_COUNT(2);
+                    p_next--;
+                    wave_sync();  // the part's blocks have been read
+                    if (misses >= TB_HARD_MISSES && p_next) {
+                        // input without signal (half of all 30-step speculations fail): no more parts in flight, the top-down loop
+                        // below takes them from the spill; the window jumps to the frame's last 17 blocks
+                        p_next = 0;
+                        base = (int)nblk - (int)LONG_LDS_BLOCKS;
+                        if ((int)rb >= base) __builtin_trap();  // cannot happen: a part that is not the last but one ends >= 32 blocks below the top
+                    } else {
+                        base += (int)DUMP_GROUP;  // the next part up (part 0 included): the carried blocks are its first ones
+                        carry_to_lds(cy, dec, dslot, 0u, nc);
+                    }
+                    if (VIT_LONG_TRACE_PRIO >= 0) __builtin_amdgcn_s_setprio(VIT_LONG_BASE_PRIO);  // (a one-round launch sets its rotating level at the next block)
+#ifdef VIT_DIAG_TIMES
+                    diag_tr += __builtin_amdgcn_s_memrealtime() - diag_ta;
+#endif
                 }
                 v = v == 4 ? 0 : v + 1;
             }
         }
-        __syncthreads();
-        img[lane] = 0;  // 4 frames x IMG_RING words (the ring aliases the dead table region)
+        // the frame's last block (window position 16) waited in the carry for the table to die
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // once per group: the spill is complete before anything is read back
+        wave_sync();
+        if ((int)nblk - 1 - base == (int)DUMP_GROUP) carry_to_lds(cy, dec, dslot, DUMP_GROUP, 1u);
 #ifdef VIT_DIAG_TIMES
         const unsigned long long diag_t1 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-        // ---- traceback: LDS tail, then the spilled blocks 16 at a time from the top ----
-        const u32 fi = lane >> 4, slot = lane & (IMG_RING - 1u);
-        const u32 t_fb = fi == 0 ? fbits[0] : fi == 1 ? fbits[1] : fi == 2 ? fbits[2] : fbits[3];
+#if VIT_TB16
+        if (fast) {
+            // ---- part 0 from the ring and the true end state, then the chain of parts from the top down: a part whose recorded
+            // top position is not what the part above ends in (or that was never traced) comes back from the spill ----
+            u32 p = 0;
+            SPEC_COUNT(0);
+            for (u32 it = 0; it <= NP; it++) {
+                if (it) {
+                    const u32 up = (u32)__shfl_up((int)rec_out, 1);
+                    const unsigned long long bad = __ballot(lane >= 1u && lane < NP && rec_spec != up);
+                    if (bad == 0) break;
+                    p = (u32)__builtin_ctzll(bad);  // the topmost such part: everything above it is final
+                    SPEC_COUNT(3);
+                    if ((u32)__builtin_amdgcn_readlane((int)rec_spec, (int)p) != 0xFFFFFFFFu) SPEC_COUNT(4);
+                }
+                const u32 hi = T_max - 256u * p;
+                const u32 lo = hi > 256u + VIT_TAIL ? hi - 256u : VIT_TAIL;
+                const u32 nl = (hi - lo) >> 4;
+                u32 slot0 = (u32)base;  // part 0 sits in the window the forward pass left behind
+                u32 ktop = 0x01010101u * P_ZERO;
+                if (p) {
+                    slot0 = lo >> 4;
+                    wave_sync();
+                    ktop = (u32)__builtin_amdgcn_readlane((int)rec_out, (int)(p - 1u));
+                    uint2 d[LONG_LDS_BLOCKS];
+#pragma unroll
+                    for (u32 k = 0; k < LONG_LDS_BLOCKS; k++) d[k] = k <= nl ? wspill[(size_t)(slot0 + k) * 64u] : make_uint2(0u, 0u);
+#pragma unroll
+                    for (u32 k = 0; k < LONG_LDS_BLOCKS; k++)
+                        if (k <= nl) *reinterpret_cast<uint2*>(dec + k * DEC_BLOCK + dslot) = d[k];
+                }
+                wave_sync();
+                const u32 P_top = (ktop >> (8u * fi)) & 0xFFu;
+                const u32 pout = traceback_part16<false, true>(dec, nullptr, 0u, lane, lo, nl, slot0, P_top, 0u, o_f);
+                const u32 ko = pack_rows(pout);
+                if (lane == p) {
+                    rec_spec = ktop;
+                    rec_out = ko;
+                }
+            }
+            wave_sync();  // the part's LDS blocks are read before the next group's pre-pass reuses the region
+#ifdef VIT_DIAG_TIMES
+            if (lane == 0 && grp < 16384u) {
+                u32 hwid;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+                g_diag_times[grp * 4u + 0u] = diag_t0;
+                g_diag_times[grp * 4u + 1u] = diag_t1;
+                g_diag_times[grp * 4u + 2u] = __builtin_amdgcn_s_memrealtime();
+                g_diag_times[grp * 4u + 3u] = diag_tr;
+            }
+#endif
+            continue;
+        }
+#endif
+        // ---- general form: LDS tail (the last 17 blocks, from the ring), then the spilled blocks 16 at a time from the top ----
+#ifndef VIT_EXP_NO_GENERAL
+        const u32 Gg = nblk > LONG_LDS_BLOCKS ? nblk - LONG_LDS_BLOCKS : 0u;  // blocks below the LDS tail (= base: the window never moved)
+        img[lane] = 0;  // 4 frames x IMG_RING words (the ring aliases the dead table region behind the 17th block)
+        wave_sync();
+        const u32 slot = lane & (IMG_RING - 1u);
         const u32 t_T = t_fb ? t_fb + VIT_TAIL : 0u;
-        uint8_t* o_f = out + (fi == 0 ? ooff[0] : fi == 1 ? ooff[1] : fi == 2 ? ooff[2] : ooff[3]);
         const u32 nbytes_f = (t_fb + 7u) >> 3;  // a partial last byte is padded with zero bits (ChainBack starts from E = 0)
         const bool o_aligned = (reinterpret_cast<uintptr_t>(o_f) & 3u) == 0;
         u32 d_hi = (t_fb + 31u) >> 5;  // image words [d_lo, d_hi) of this lane's frame are not written out yet
@@ -1118,7 +1351,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
         // 4 MSB-first bytes (deconvolve.cpp:432-433) and the slot is cleared for the words further down.
         auto flush = [&](const u32 ts_done) {
             const u32 d_lo = ts_done <= VIT_TAIL ? 0u : (ts_done - VIT_TAIL + 31u) >> 5;
-            __syncthreads();  // all atomicOr of the part have landed
+            wave_sync();  // all atomicOr of the part have landed
             const u32 d = d_lo + ((slot - d_lo) & (IMG_RING - 1u));
             if (d < d_hi) {
                 const u32 v = __builtin_bswap32(__builtin_bitreverse32(img[lane]));  // byte k = bit-reversed byte k
@@ -1133,10 +1366,10 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
                 }
             }
             d_hi = d_hi < d_lo ? d_hi : d_lo;
-            __syncthreads();
+            wave_sync();
         };
         u32* scratch = reinterpret_cast<u32*>(tab + DEC_BLOCK) + lane * pk_scratch_words(lay.maxfb);
-        const u32 t_lo = G * 16u;
+        const u32 t_lo = Gg * 16u;
         const u32 ts_top = t_lo > VIT_TAIL ? t_lo : VIT_TAIL;
         // the spilled blocks come back 16 at a time; a group is fetched into registers while the part above it
         // is being traced back, so its HBM latency is off the wave's critical path
@@ -1146,54 +1379,17 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
             for (u32 k = 0; k < DUMP_GROUP; k++)
                 d[k] = (g0 + k < g1) ? wspill[(size_t)(g0 + k) * 64u] : make_uint2(0u, 0u);
         };
-        if (G) fetch(G > DUMP_GROUP ? G - DUMP_GROUP : 0u, G);
-#if VIT_TB16
-        if (fbits[0] == fbits[1] && fbits[1] == fbits[2] && fbits[2] == fbits[3] && (maxfb & 15u) == 0) {
-            // ---- fast form (see traceback_part16): 256-step parts from the top; the 17-block window moves down through the
-            // spilled blocks, the next group is in flight (in registers) while a part is traced back ----
-            u32 hi = T_max, slot0 = G, P16 = P_ZERO;
-            for (;;) {
-                const u32 lo = hi > 256u + VIT_TAIL ? hi - 256u : VIT_TAIL;
-                P16 = traceback_part16(dec, img, IMG_RING, lane, lo, (hi - lo) >> 4, slot0, P16, IMG_RING - 1u);
-                flush(lo);
-                if (lo == VIT_TAIL) break;
-                const u32 dn = slot0 < DUMP_GROUP ? slot0 : DUMP_GROUP;  // the fetched group is blocks [slot0 - dn, slot0)
-                __syncthreads();
-                for (u32 sl = DUMP_GROUP; sl >= dn; sl--) {  // what stays moves dn slots up (dn >= 1 here)
-                    *reinterpret_cast<uint2*>(dec + sl * DEC_BLOCK + dslot) = *reinterpret_cast<const uint2*>(dec + (sl - dn) * DEC_BLOCK + dslot);
-                }
-#pragma unroll
-                for (u32 k = 0; k < DUMP_GROUP; k++)
-                    if (k < dn) *reinterpret_cast<uint2*>(dec + k * DEC_BLOCK + dslot) = d[k];
-                __syncthreads();
-                slot0 -= dn;
-                if (slot0) fetch(slot0 > DUMP_GROUP ? slot0 - DUMP_GROUP : 0u, slot0);
-                hi = lo;
-            }
-            __syncthreads();
-#ifdef VIT_DIAG_TIMES
-            if (lane == 0 && grp < 16384u) {
-                u32 hwid;
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-                g_diag_times[grp * 4u + 0u] = diag_t0;
-                g_diag_times[grp * 4u + 1u] = diag_t1;
-                g_diag_times[grp * 4u + 2u] = __builtin_amdgcn_s_memrealtime();
-                g_diag_times[grp * 4u + 3u] = hwid;
-            }
-#endif
-            continue;
-        }
-#endif
+        if (Gg) fetch(Gg > DUMP_GROUP ? Gg - DUMP_GROUP : 0u, Gg);
         u32 warm = TB_WARM;
-        u32 P_part = traceback_part(dec, scratch, img, IMG_RING, lane, ts_top, t_T, T_max, G, P_ZERO, warm, IMG_RING - 1u);
+        u32 P_part = traceback_part(dec, scratch, img, IMG_RING, lane, ts_top, t_T, T_max, Gg, P_ZERO, warm, IMG_RING - 1u);
         flush(ts_top);
-        for (u32 g1 = G; g1 > 0;) {
+        for (u32 g1 = Gg; g1 > 0;) {
             const u32 g0 = g1 > DUMP_GROUP ? g1 - DUMP_GROUP : 0u;
-            __syncthreads();
+            wave_sync();
 #pragma unroll
             for (u32 k = 0; k < DUMP_GROUP; k++)
                 *reinterpret_cast<uint2*>(dec + k * DEC_BLOCK + dslot) = d[k];
-            __syncthreads();
+            wave_sync();
             if (g0) fetch(g0 > DUMP_GROUP ? g0 - DUMP_GROUP : 0u, g0);  // next group down, in flight during this part
             const u32 tsg = g0 ? g0 * 16u : VIT_TAIL, tend = g1 * 16u;
             const u32 te = t_T < tend ? t_T : tend, te_max = T_max < tend ? T_max : tend;
@@ -1202,7 +1398,8 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
             flush(tsg);
             g1 = g0;
         }
-        __syncthreads();  // the image is read before the next group's pre-pass reuses the region
+        wave_sync();  // the image is read before the next group's pre-pass reuses the region
+#endif
     }
 }
 
@@ -1211,6 +1408,15 @@ constexpr u32 PK_SHORT_MAX = SEG_BLOCKS * 16u - VIT_TAIL;  // 778: the longest f
 
 }  // namespace
 
+#ifdef VIT_DIAG_SPEC
+extern "C" __attribute__((visibility("default"))) int vit_diag_spec(void* host_buf, int reset) {
+    if (reset) {
+        unsigned long long z[8] = {};
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_diag_spec), z, sizeof z);
+    }
+    return (int)hipMemcpyFromSymbol(host_buf, HIP_SYMBOL(g_diag_spec), sizeof(unsigned long long) * 8);
+}
+#endif
 #ifdef VIT_DIAG_TIMES
 extern "C" __attribute__((visibility("default"))) int vit_diag_times(void* host_buf) {
     return (int)hipMemcpyFromSymbol(host_buf, HIP_SYMBOL(g_diag_times), sizeof(unsigned long long) * 16384 * 4);
@@ -1322,7 +1528,7 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
         launch_short(grid, lay, lay.maxfb, nullptr, true);
         return hipGetLastError();
     }
-    const u32 spill_blocks = is_long ? nblk - LONG_LDS_BLOCKS : 0u;
+    const u32 spill_blocks = is_long ? nblk - LONG_KEEP : 0u;
     const size_t desc_bytes = sort ? (((size_t)nframes * sizeof(vit_frame_desc) + 255u) & ~(size_t)255u) : 0u;
     const size_t need = SCRATCH_HDR + desc_bytes + (size_t)grid * spill_blocks * DEC_BLOCK;
     if (dev < 0 || dev >= PK_MAX_DEVS) return hipErrorInvalidDevice;

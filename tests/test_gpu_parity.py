@@ -64,6 +64,58 @@ def test_decode_parity_long_frames(V, O, torch_cuda, framebits, kernel):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("framebits", [784, 1008, 1040, 3072, 6912, 9216])
+def test_long_frames_in_flight_parts(V, O, torch_cuda, framebits):
+    """the long-frame kernel's in-flight parts (csrc/vit_pk.hip, round 4: a group of four equally long frames is traced back
+    256 steps at a time WHILE the add-compare-select runs ahead, from a speculative top position; the chain of recorded
+    positions is checked after the forward pass and a part that fails comes back from the write-only spill) on the input
+    families that take each of its paths: Eb/N0 3 dB (about 1 % of the wave-parts fail their check), 2 dB (7 %), 1 dB (most
+    waves give up tracing in flight after their first part), 0 dB / uniform random bytes / hard decisions (all give up) -
+    tests/tools/spec_stats.py counts them on a -DVIT_DIAG_SPEC build (profiles/r04_spec_stats.jsonl)"""
+    n = 192 if framebits <= 3072 else 96
+    fams = [O.noisy_frames(n, framebits, seed=framebits + 11),
+            O.noisy_frames(n, framebits, seed=framebits + 12, ebn0_db=2.0),
+            O.noisy_frames(n, framebits, seed=framebits + 13, ebn0_db=1.0),
+            O.noisy_frames(n // 2, framebits, seed=framebits + 14, ebn0_db=0.0),
+            O.uniform_symbols((n // 2) * O.sym_len(framebits), seed=framebits + 15).reshape(n // 2, -1),
+            O.hard_flipped_frames(n // 2, framebits, flip=0.1, seed=framebits + 16)]
+    sym = np.concatenate(fams)
+    want = O.decode_batch(framebits, sym, nthreads=8)
+    got = _gpu_decode(V, torch_cuda, sym, framebits, 2)
+    bad = np.flatnonzero((got != want).any(axis=1))
+    assert bad.size == 0, "frames %s differ" % bad[:8]
+
+
+def test_long_frames_in_flight_parts_in_a_descriptor_table(V, O, torch_cuda):
+    """the same through the variable-length entry: groups of four equal lengths take the in-flight form, groups that
+    straddle two lengths (and lengths that are not a multiple of 16) the general form - both inside one launch, every
+    frame compared"""
+    import torch
+    rng = np.random.default_rng(44)
+    lens = [6912] * 10 + [4608] * 9 + [3072] * 7 + [1000] * 5 + [784] * 6 + [782] * 3 + [9216] * 2 + [288] * 5
+    rng.shuffle(lens)
+    syms, wants, descs, so, oo = [], [], [], 0, 0
+    for i, fb in enumerate(lens):
+        s = O.noisy_frames(1, fb, seed=1000 + i, ebn0_db=(3.0 if i % 3 else 2.0))[0]
+        syms.append(s)
+        wants.append(O.decode_batch(fb, s[None, :])[0])
+        descs.append((so, oo, fb, 0))
+        so += s.size
+        oo += (fb + 7) // 8
+    d_sym = torch.from_numpy(np.concatenate(syms)).cuda()
+    d_out = torch.full((oo,), 0xEE, dtype=torch.uint8, device="cuda")
+    desc = np.array(descs, dtype=V.DESC_DTYPE)
+    old = V.set_kernel(2)
+    try:
+        V.decode_varlen_dev(d_sym, d_out, torch.from_numpy(desc.view(np.uint8)).cuda(), len(lens), max(lens))
+        torch.cuda.synchronize()
+    finally:
+        V.set_kernel(old)
+    got = d_out.cpu().numpy()
+    for (so, oo, fb, _), w in zip(descs, wants):
+        assert np.array_equal(got[oo:oo + (fb + 7) // 8], w), fb
+
+
 def test_fast_traceback_form_every_multiple_of_16(V, O, torch_cuda):
     """the straight-line traceback form (csrc/vit_pk.hip traceback_part16: waves of four equally long frames, a multiple
     of 16 bits) over EVERY such length up to 1600 bits - all register/LDS window shapes of the single-segment kernel

@@ -99,9 +99,21 @@ void probe_devices() {
     // is early enough (before the process's first HIP call) and GPU_MAX_HW_QUEUES is not set already.
     if (const char* q = getenv("VITERBI_AMD_HW_QUEUES"))
         if (atoi(q) > 0) setenv("GPU_MAX_HW_QUEUES", q, 0);
+    // The first HIP call of a process can fail transiently right after another process has released the GPU (seen once on a
+    // freshly acquired box: torch saw the device, this probe did not).  The probe runs once per process, so it does not give up
+    // at the first answer: up to 2 s of retries, and the error text says what HIP reported.
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    hipError_t pe = hipSuccess;
+    for (int attempt = 0; attempt < 20; attempt++) {
+        pe = hipGetDeviceCount(&n);
+        if (pe == hipSuccess && n > 0) break;
         (void)hipGetLastError();
+        n = 0;
+        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    }
+    if (n <= 0) {
+        snprintf(g_init_err, sizeof g_init_err, "no usable gfx950 (MI355X) HIP device (hipGetDeviceCount: %s); libviterbi has no CPU path",
+                 pe == hipSuccess ? "0 devices" : hipGetErrorString(pe));
         g_ndev = 0;
         g_device = -1;
         return;
@@ -819,6 +831,7 @@ const char* vit_last_error(void) { return t_err; }
 
 int vit_device_count(void) {
     ensure_init();
+    if (g_ndev == 0) set_err("%s", g_init_err);
     return g_ndev;
 }
 

@@ -51,8 +51,8 @@ for (name, grid), c in sorted(agg.items()):
     rd = 2.0 * c.get("FETCH_SIZE", 0) * 1024
     wr = c.get("WRITE_SIZE", 0) * 1024
     out.append("%-48s grid=%-9s read %9.1f MB  write %9.1f MB\n" % (name, grid, rd / 1e6, wr / 1e6))
-out.append("\n# reading the table: config 5 (grid 229376 = 3584 persistent workgroups, 81920 frames of 4608 bits) reads 1512 MB of\n"
-           "# symbols + 2852 MB of spilled decisions and writes 2852 MB of spill + 47 MB of output: the spill is 16 B per\n"
-           "# frame-step by design (DESIGN.md), 7.2 GB per 3.85 ms launch = 1.9 TB/s on a VALU-bound kernel.\n")
+out.append("\n# reading the table: launches are grouped by kernel and grid only, so several cases of bench_configs.py share a line (4096 persistent\n"
+           "# workgroups = grid 262144: config 3, config 5 and the multi-round uniform cases).  Per-case traffic against the algorithmic bytes is in\n"
+           "# %s_traffic_long.jsonl (tools/exp/pmc_traffic_long.sh).\n" % tag)
 open(os.path.join(dst, "%s_config_kernels.txt" % tag), "w").writelines(out)
 print("".join(out))

@@ -17,7 +17,11 @@ with open(os.path.join(dst, "%s_other_configs.jsonl" % tag), "w") as f:
         for line in open(os.path.join(src, name)):
             if line.startswith("{"):
                 f.write(line)
-shutil.copy(os.path.join(src, "vitbench.txt"), os.path.join(dst, "%s_vitbench.txt" % tag))
+with open(os.path.join(dst, "%s_vitbench.txt" % tag), "w") as f:
+    f.write("# %s: tools/vitbench.cpp (tools/collect_config_profiles.sh) on one MI355X box: the five reference exports only (dlopen, no HIP in the\n"
+            "# harness); every multi-thread result compared with the single-call result; 'ingest stage on (defaults)': window 50 us, min_callers 1,\n"
+            "# depth 4, spin_cpus = CPU budget / 4\n" % tag)
+    f.write(open(os.path.join(src, "vitbench.txt")).read())
 if os.path.exists(os.path.join(src, "small_batch.jsonl")):
     with open(os.path.join(dst, "%s_small_batch.jsonl" % tag), "w") as f:
         f.writelines(l for l in open(os.path.join(src, "small_batch.jsonl")) if l.startswith("{"))

@@ -29,9 +29,9 @@
 // 49 blocks (784 steps) the first 32 blocks of history stay in VGPRs (two 32-dword
 // register arrays indexed with s_set_gpr_idx), 16 go to LDS and the last one to the
 // start of the then-dead metric table: 10 KB of LDS per wave, 16 waves per CU.
-// Longer frames (vit_pk_long_kernel): same forward pass, but every block except the last 17 is
-// spilled to a per-workgroup slice of HBM (8 B per frame-step each way - the path is VALU-bound and
-// HBM has >90 % headroom) and reloaded 16 blocks at a time for the traceback.
+// Longer frames (vit_pk_long_kernel): same forward pass; the frame is traced back 256 steps at a time WHILE
+// the pass runs, from a 16-block window in LDS, and every block is also written - once, 8 B per frame-step -
+// to a per-workgroup slice of HBM from which only a part that fails its check is read back.
 //
 // Traceback.  Per segment three parts (LDS tail, then the register blocks 16 at a
 // time through the same LDS region), each blocked and speculative: lane = (frame,
@@ -907,26 +907,26 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
     }
 }
 
-// ---- frames longer than one segment: decisions go through a 32-block register ring and, write-only, through HBM ---------
+// ---- frames longer than one segment: traced back in flight from a window in LDS; decisions written once to HBM -------------
 // (history: round 1 checkpoint + recompute, 1.7x the ACS work; rounds 2-3 one forward pass whose blocks were spilled to HBM and
 // read back 16 at a time for a traceback after the forward pass: 8 B per frame-step each way.)
-// Round 4: the forward pass keeps the last 32 blocks of history in VGPRs (the ring the single-segment kernel uses) and writes every
-// block but the last 16 to the workgroup's slice of `spill` (512 B per block, coalesced) WITHOUT reading it back:
+// Round 4: the forward pass writes every block but a frame's last 16 to the workgroup's slice of `spill` (512 B per block,
+// coalesced) WITHOUT reading it back, and keeps what a traceback may need next in a window of LDS (see below):
 //   * a group of four equally long frames of a multiple of 16 bits (every DAB size) is traced back IN FLIGHT.  Its frames are cut
 //     into parts of 256 steps from the top (part 0 = the frame's end); as soon as the ACS is two blocks past the top of part p >= 1,
-//     at the next point where the branch-metric table is dead (so that 19 blocks fit the workgroup's 10 KB of LDS), the part's 17
-//     blocks and the two above go from the ring to LDS and the part is traced speculatively (traceback_part16<SPEC>: every lane 30
-//     steps above its block from state 0, the top lane trusted), its decoded bits go straight to `out`, and the position at its top
-//     (spec) and at its bottom (out) are recorded - lane p of two registers holds part p, four frames x 8 bits.
+//     at the next point where the branch-metric table is dead (so that 19 blocks fit the workgroup's 10 KB of LDS), the part is
+//     traced speculatively (traceback_part16<SPEC>: every lane 30 steps above its block from state 0, the top lane trusted), its
+//     decoded bits go straight to `out`, and the position at its top (spec) and at its bottom (out) are recorded - lane p of two
+//     registers holds part p, four frames x 8 bits.
 //   * after the forward pass part 0 is traced from the true end state (state 0), and the chain is checked from the top down:
-//     part p is final iff spec(p) = out(p - 1).  The first part that fails - 0.35 % of the frame-parts at Eb/N0 = 3 dB
-//     (profiles/r03_merge_depth.txt) - is reloaded from the spill (17 blocks), traced from its true top and checked again:
+//     part p is final iff spec(p) = out(p - 1).  The first part that fails - 1.1 % of the wave-parts at Eb/N0 = 3 dB, 7 % at 2 dB
+//     (profiles/r04_spec_stats.jsonl) - is reloaded from the spill (17 blocks), traced from its true top and checked again:
 //     the fixed point is the serial ChainBack (deconvolve.cpp:416-435), as before.
 //   * a wave whose first in-flight part shows >= TB_HARD_MISSES missed blocks (input without signal: half of all 30-step
 //     speculations fail) stops tracing in flight: its parts stay marked "unchecked" and the top-down loop traces them all from
 //     the spill - the behaviour of rounds 2-3.
 //   * other groups (mixed lengths in a wave, lengths that are not a multiple of 16) take the general traceback form after the
-//     forward pass, last 17 blocks from the ring, the others read back from the spill as before.
+//     forward pass: the last 17 blocks from the window, the others read back from the spill as before.
 // Workgroups are persistent: each takes the next group of 4 frames from an atomic counter, so the spill buffer is sized by the
 // resident waves, not by the batch, and a length-sorted descriptor table is consumed longest-first.
 constexpr u32 LONG_LDS_BLOCKS = DUMP_GROUP + 1u;  // 17: the blocks of one 256-step part
@@ -1284,7 +1284,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
 
 #if VIT_TB16
         if (fast) {
-            // ---- part 0 from the ring and the true end state, then the chain of parts from the top down: a part whose recorded
+            // ---- part 0 from the window and the true end state, then the chain of parts from the top down: a part whose recorded
             // top position is not what the part above ends in (or that was never traced) comes back from the spill ----
             u32 p = 0;
             SPEC_COUNT(0);
@@ -1336,8 +1336,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
             continue;
         }
 #endif
-        // ---- general form: LDS tail (the last 17 blocks, from the ring), then the spilled blocks 16 at a time from the top ----
-#ifndef VIT_EXP_NO_GENERAL
+        // ---- general form: LDS tail (the last 17 blocks: the window), then the spilled blocks 16 at a time from the top ----
         const u32 Gg = nblk > LONG_LDS_BLOCKS ? nblk - LONG_LDS_BLOCKS : 0u;  // blocks below the LDS tail (= base: the window never moved)
         img[lane] = 0;  // 4 frames x IMG_RING words (the ring aliases the dead table region behind the 17th block)
         wave_sync();
@@ -1399,7 +1398,6 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
             g1 = g0;
         }
         wave_sync();  // the image is read before the next group's pre-pass reuses the region
-#endif
     }
 }
 

@@ -374,7 +374,7 @@ def test_deconvolve_ring_many_callers_and_comparator(V, O, torch_cuda):
         V.set_batch_window_us(old)
 
 
-@pytest.mark.parametrize("framebits,n", [(768, 50), (3072, 9), (24, 5)])
+@pytest.mark.parametrize("framebits,n", [(768, 50), (3072, 9), (24, 5), (6912, 40)])
 def test_u32_ingest_path(V, O, torch_cuda, framebits, n):
     """the reference ABI's u32-per-symbol format resident on the device (only the low byte counts,
     deconvolve.cpp:158-165): read in place by the packed kernels (short and long frames), narrowed by the

@@ -1256,12 +1256,12 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
                     if (misses >= TB_HARD_MISSES && p_next > 1u) SPEC_COUNT(2);
                     p_next--;
                     wave_sync();  // the part's blocks have been read
-                    if (misses >= TB_HARD_MISSES && p_next) {
+                    if (misses >= TB_HARD_MISSES && p_next && (int)rb < (int)nblk - (int)LONG_LDS_BLOCKS) {
                         // input without signal (half of all 30-step speculations fail): no more parts in flight, the top-down loop
-                        // below takes them from the spill; the window jumps to the frame's last 17 blocks
+                        // below takes them from the spill; the window jumps to the frame's last 17 blocks (always ahead of the ACS
+                        // here: a part that is not the last but one ends >= 32 blocks below the top - the test is belt and braces)
                         p_next = 0;
                         base = (int)nblk - (int)LONG_LDS_BLOCKS;
-                        if ((int)rb >= base) __builtin_trap();  // cannot happen: a part that is not the last but one ends >= 32 blocks below the top
                     } else {
                         base += (int)DUMP_GROUP;  // the next part up (part 0 included): the carried blocks are its first ones
                         carry_to_lds(cy, dec, dslot, 0u, nc);

@@ -770,6 +770,8 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
         auto sa = load_step<SYM32>(a_sym, tau, tau < a_T), sb = load_step<SYM32>(b_sym, tau, tau < b_T);
         u32 v = 0;
         for (u32 rb = 0; rb < nb; rb++) {
+            u32 rbs = rb;
+            asm volatile("" : "+s"(rbs));  // addresses are formed from the scalar block index where they are used: as induction variables they cost two VALU adds in every block
             if constexpr (ROT) {
                 switch ((prio_slot + rb) & 3u) {
                     case 0: __builtin_amdgcn_s_setprio(0); break;
@@ -781,18 +783,19 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
             if ((rb & 1u) == 0) {
                 __syncthreads();  // every lane is done with the previous table
                 prepass(pack_step(sa), pack_step(sb), tab, PL, sel);
-                const u32 tn = (rb + 2u) * 16u + tau;
+                const u32 tn = (rbs + 2u) * 16u + tau;
                 sa = load_step<SYM32>(a_sym, tn, tn < a_T);  // prefetch the next 32 steps' symbols
                 sb = load_step<SYM32>(b_sym, tn, tn < b_T);
                 __syncthreads();
             }
 #if VIT_TAB_STATIC
-            if (VIT_STEPS6 && rb + 1u == nb && (T_max & 15u) == 6u) {
-                if (rb & 1u) steps6(v, A, B, acc0, acc1, tab, L1, lane, C);
-                else steps6(v, A, B, acc0, acc1, tab, L, lane, C);
-            } else {
-                if (rb & 1u) steps16<true>(v, A, B, acc0, acc1, tab, L1, lane, C);
-                else steps16<true>(v, A, B, acc0, acc1, tab, L, lane, C);
+            // ONE scalar switch over (last short block, table half): as nested ifs the block's parity travelled from the loop head to here
+            // through a VGPR (v_cndmask + v_cmp in every block)
+            switch (((VIT_STEPS6 && rb + 1u == nb && (T_max & 15u) == 6u) ? 2u : 0u) | (rb & 1u)) {
+                case 0: steps16<true>(v, A, B, acc0, acc1, tab, L, lane, C); break;
+                case 1: steps16<true>(v, A, B, acc0, acc1, tab, L1, lane, C); break;
+                case 2: steps6(v, A, B, acc0, acc1, tab, L, lane, C); break;
+                default: steps6(v, A, B, acc0, acc1, tab, L1, lane, C); break;
             }
 #else
             if (VIT_STEPS6 && rb + 1u == nb && (T_max & 15u) == 6u)
@@ -805,7 +808,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
                 r1[rb] = acc1;
             } else {
                 if (rb + 1u == nb) __syncthreads();  // the last block lands on the table: all reads done first
-                *reinterpret_cast<uint2*>(dec + (rb - R) * DEC_BLOCK + dslot) = make_uint2(acc1, acc0);
+                *reinterpret_cast<uint2*>(dec + (rbs - R) * DEC_BLOCK + dslot) = make_uint2(acc1, acc0);
             }
             v = v == 4 ? 0 : v + 1;
         }
@@ -1288,6 +1291,17 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
             // top position is not what the part above ends in (or that was never traced) comes back from the spill ----
             u32 p = 0;
             SPEC_COUNT(0);
+            uint2 d[LONG_LDS_BLOCKS];  // a part's 17 blocks on their way from the spill to LDS
+#pragma unroll
+            for (u32 k = 0; k < LONG_LDS_BLOCKS; k++) d[k] = make_uint2(0u, 0u);
+            u32 pre = 0;               // the part whose blocks were requested ahead (0 = none)
+            auto request = [&](const u32 q) {  // issue the loads of part q's blocks
+                const u32 qhi = T_max - 256u * q;
+                const u32 qlo = qhi > 256u + VIT_TAIL ? qhi - 256u : VIT_TAIL;
+                const u32 qb = qlo >> 4, qn = (qhi - qlo) >> 4;
+#pragma unroll
+                for (u32 k = 0; k < LONG_LDS_BLOCKS; k++) d[k] = k <= qn ? wspill[(size_t)(qb + k) * 64u] : make_uint2(0u, 0u);
+            };
             for (u32 it = 0; it <= NP; it++) {
                 if (it) {
                     const u32 up = (u32)__shfl_up((int)rec_out, 1);
@@ -1306,12 +1320,21 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
                     slot0 = lo >> 4;
                     wave_sync();
                     ktop = (u32)__builtin_amdgcn_readlane((int)rec_out, (int)(p - 1u));
-                    uint2 d[LONG_LDS_BLOCKS];
-#pragma unroll
-                    for (u32 k = 0; k < LONG_LDS_BLOCKS; k++) d[k] = k <= nl ? wspill[(size_t)(slot0 + k) * 64u] : make_uint2(0u, 0u);
+                    if (pre != p) request(p);
 #pragma unroll
                     for (u32 k = 0; k < LONG_LDS_BLOCKS; k++)
                         if (k <= nl) *reinterpret_cast<uint2*>(dec + k * DEC_BLOCK + dslot) = d[k];
+                }
+                // (option) the part below was never traced (a wave that gave up tracing in flight): it is certain to come next, so its
+                // blocks could be requested now and arrive while this part is traced, as rounds 2-3 hid the read-back latency
+                pre = 0;
+#ifndef VIT_LONG_PREFETCH
+#define VIT_LONG_PREFETCH 0  /* measured, not adopted: config 3 on input without signal 1.37 ms without, 1.39 ms with (profiles/r04_ab_long_inflight.txt §7) */
+#endif
+                if (VIT_LONG_PREFETCH && p + 1u < NP && (u32)__builtin_amdgcn_readlane((int)rec_spec, (int)(p + 1u)) == 0xFFFFFFFFu) {
+                    wave_sync();  // the stores above have taken their data
+                    request(p + 1u);
+                    pre = p + 1u;
                 }
                 wave_sync();
                 const u32 P_top = (ktop >> (8u * fi)) & 0xFFu;
@@ -1373,6 +1396,9 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
         // the spilled blocks come back 16 at a time; a group is fetched into registers while the part above it
         // is being traced back, so its HBM latency is off the wave's critical path
         uint2 d[DUMP_GROUP];
+#pragma unroll
+        for (u32 k = 0; k < DUMP_GROUP; k++) d[k] = make_uint2(0u, 0u);  // defined on EVERY path: left undefined on the path without a fetch, the array counted as live
+                                                                          // across the whole group loop - 29 more VGPRs (128 instead of 99) and 2-6 % of the 3 dB rate (r04_ab_long_inflight.txt §7)
         auto fetch = [&](const u32 g0, const u32 g1) {
 #pragma unroll
             for (u32 k = 0; k < DUMP_GROUP; k++)

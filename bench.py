@@ -19,6 +19,7 @@ peak with the ALGORITHMIC bytes (3192 B per FIC frame: 3096 symbol bytes in + 96
 import argparse
 import json
 import os
+import random
 import socket
 import subprocess
 import sys
@@ -327,7 +328,28 @@ def parse_args(argv=None):
 
 
 def _free_port():
-    s = socket.socket()
+    """A rendezvous port for ranks that start seconds from now.  NOT bind(0): that hands out a port of the kernel's ephemeral range
+    (ip_local_port_range, 32768-60999 here), which any outgoing connection of any process may take before rank 0 listens on it (seen
+    once: EADDRINUSE in the spawn test).  A random port BELOW that range that can be bound right now is only ever taken by another
+    listener."""
+    lo_eph = 32768
+    try:
+        lo_eph = int(open("/proc/sys/net/ipv4/ip_local_port_range").read().split()[0])
+    except (OSError, ValueError, IndexError):
+        pass
+    hi = max(min(lo_eph, 32768) - 1, 12000)
+    rng = random.Random(os.getpid() ^ int(time.time() * 1e6))
+    for _ in range(64):
+        port = rng.randint(10000, hi)
+        s = socket.socket()
+        try:
+            s.bind(("127.0.0.1", port))
+        except OSError:
+            continue
+        finally:
+            s.close()
+        return port
+    s = socket.socket()  # last resort
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()

@@ -14,11 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """bench.py's choice: a bindable port BELOW the kernel's ephemeral range (a bind(0) port can be taken by any outgoing
+    connection before the ranks listen on it)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench._free_port()
 
 
 def _worker(rank, world, port, nframes, framebits, q, pipeline=None):

@@ -769,48 +769,47 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
     {
         auto sa = load_step<SYM32>(a_sym, tau, tau < a_T), sb = load_step<SYM32>(b_sym, tau, tau < b_T);
         u32 v = 0;
-        for (u32 rb = 0; rb < nb; rb++) {
+        // Two blocks per trip - the pre-pass's 32 steps: the even block reads table half 0, the odd one half 1.  (One block per trip cost
+        // four v_mov of loop-carried values per block; per pair of blocks it is the same four.)
+        const bool last6 = VIT_STEPS6 && (T_max & 15u) == 6u;  // the frame's last block has six steps
+        auto put = [&](const u32 rbx) {  // the block's history words: registers for blocks < R, else LDS (the last one on the dead table)
+            u32 rbs = rbx;
+            asm volatile("" : "+s"(rbs));  // the address is formed from the scalar block index here: as an induction variable it cost a VALU add in every block
+            if (rbx < R) {
+                r0[rbx] = acc0;  // s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off
+                r1[rbx] = acc1;
+            } else {
+                if (rbx + 1u == nb) __syncthreads();  // the last block lands on the table: all reads done first
+                *reinterpret_cast<uint2*>(dec + (rbs - R) * DEC_BLOCK + dslot) = make_uint2(acc1, acc0);
+            }
+        };
+        for (u32 rb = 0; rb < nb; rb += 2u) {
             u32 rbs = rb;
-            asm volatile("" : "+s"(rbs));  // addresses are formed from the scalar block index where they are used: as induction variables they cost two VALU adds in every block
+            asm volatile("" : "+s"(rbs));
             if constexpr (ROT) {
-                switch ((prio_slot + rb) & 3u) {
+                switch ((prio_slot + (rb >> 1)) & 3u) {
                     case 0: __builtin_amdgcn_s_setprio(0); break;
                     case 1: __builtin_amdgcn_s_setprio(1); break;
                     case 2: __builtin_amdgcn_s_setprio(2); break;
                     default: __builtin_amdgcn_s_setprio(3); break;
                 }
             }
-            if ((rb & 1u) == 0) {
-                __syncthreads();  // every lane is done with the previous table
-                prepass(pack_step(sa), pack_step(sb), tab, PL, sel);
-                const u32 tn = (rbs + 2u) * 16u + tau;
-                sa = load_step<SYM32>(a_sym, tn, tn < a_T);  // prefetch the next 32 steps' symbols
-                sb = load_step<SYM32>(b_sym, tn, tn < b_T);
-                __syncthreads();
-            }
-#if VIT_TAB_STATIC
-            // ONE scalar switch over (last short block, table half): as nested ifs the block's parity travelled from the loop head to here
-            // through a VGPR (v_cndmask + v_cmp in every block)
-            switch (((VIT_STEPS6 && rb + 1u == nb && (T_max & 15u) == 6u) ? 2u : 0u) | (rb & 1u)) {
-                case 0: steps16<true>(v, A, B, acc0, acc1, tab, L, lane, C); break;
-                case 1: steps16<true>(v, A, B, acc0, acc1, tab, L1, lane, C); break;
-                case 2: steps6(v, A, B, acc0, acc1, tab, L, lane, C); break;
-                default: steps6(v, A, B, acc0, acc1, tab, L1, lane, C); break;
-            }
-#else
-            if (VIT_STEPS6 && rb + 1u == nb && (T_max & 15u) == 6u)
-                steps6(v, A, B, acc0, acc1, tab + (rb & 1u) * 1024u, L, lane, C);
-            else
-                steps16<true>(v, A, B, acc0, acc1, tab + (rb & 1u) * 1024u, L, lane, C);
-#endif
-            if (rb < R) {
-                r0[rb] = acc0;  // s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off
-                r1[rb] = acc1;
-            } else {
-                if (rb + 1u == nb) __syncthreads();  // the last block lands on the table: all reads done first
-                *reinterpret_cast<uint2*>(dec + (rbs - R) * DEC_BLOCK + dslot) = make_uint2(acc1, acc0);
-            }
+            __syncthreads();  // every lane is done with the previous table
+            prepass(pack_step(sa), pack_step(sb), tab, PL, sel);
+            const u32 tn = (rbs + 2u) * 16u + tau;
+            sa = load_step<SYM32>(a_sym, tn, tn < a_T);  // prefetch the next 32 steps' symbols
+            sb = load_step<SYM32>(b_sym, tn, tn < b_T);
+            __syncthreads();
+            if (last6 && rb + 1u == nb) steps6(v, A, B, acc0, acc1, tab, L, lane, C);
+            else steps16<true>(v, A, B, acc0, acc1, tab, L, lane, C);
+            put(rb);
             v = v == 4 ? 0 : v + 1;
+            if (rb + 1u < nb) {
+                if (last6 && rb + 2u == nb) steps6(v, A, B, acc0, acc1, tab, L1, lane, C);
+                else steps16<true>(v, A, B, acc0, acc1, tab, L1, lane, C);
+                put(rb + 1u);
+                v = v == 4 ? 0 : v + 1;
+            }
         }
     }
     __syncthreads();

@@ -786,14 +786,17 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
         for (u32 rb = 0; rb < nb; rb += 2u) {
             u32 rbs = rb;
             asm volatile("" : "+s"(rbs));
-            if constexpr (ROT) {
-                switch ((prio_slot + (rb >> 1)) & 3u) {
-                    case 0: __builtin_amdgcn_s_setprio(0); break;
-                    case 1: __builtin_amdgcn_s_setprio(1); break;
-                    case 2: __builtin_amdgcn_s_setprio(2); break;
-                    default: __builtin_amdgcn_s_setprio(3); break;
+            auto rotate = [&](const u32 rbx) {  // one-round launches: the issue priority rotates block by block
+                if constexpr (ROT) {
+                    switch ((prio_slot + rbx) & 3u) {
+                        case 0: __builtin_amdgcn_s_setprio(0); break;
+                        case 1: __builtin_amdgcn_s_setprio(1); break;
+                        case 2: __builtin_amdgcn_s_setprio(2); break;
+                        default: __builtin_amdgcn_s_setprio(3); break;
+                    }
                 }
-            }
+            };
+            rotate(rb);
             __syncthreads();  // every lane is done with the previous table
             prepass(pack_step(sa), pack_step(sb), tab, PL, sel);
             const u32 tn = (rbs + 2u) * 16u + tau;
@@ -805,6 +808,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_kernel(const uint8_t* __restrict
             put(rb);
             v = v == 4 ? 0 : v + 1;
             if (rb + 1u < nb) {
+                rotate(rb + 1u);
                 if (last6 && rb + 2u == nb) steps6(v, A, B, acc0, acc1, tab, L1, lane, C);
                 else steps16<true>(v, A, B, acc0, acc1, tab, L1, lane, C);
                 put(rb + 1u);

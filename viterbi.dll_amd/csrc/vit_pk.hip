@@ -1124,6 +1124,25 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
         grp = (u32)__builtin_amdgcn_readfirstlane((int)grp);
 #endif
         if (grp >= ngroups) break;
+#ifndef VIT_LONG_TAILPRIO
+#define VIT_LONG_TAILPRIO 1
+#endif
+#if VIT_LONG_TAILPRIO
+        // The launch's LAST round of fetches (nothing replaces a wave that finishes it): the issue priority grows with the fetch order, one
+        // level per quarter of the round, so the waves that start their last group late get the slots first and a SIMD's last waves finish
+        // closer together.  Uniform launches of >= 2.25 rounds only: measured over 1 ... 10 rounds x four frame lengths
+        // (profiles/r04_ab_long_inflight.txt, section 13) it takes 3-11 % off 2.5 ... 5 rounds (config 5's decode, 5 rounds: -3 %), is within
+        // +-2 % from 5.5 rounds up, costs 7 % at exactly two rounds (all waves fetch together: the levels only unbalance them) and 2-3 % on a
+        // length-sorted table, whose last fetches are its shortest frames.
+        if (!desc && (unsigned long long)ngroups * 4ull >= 9ull * gridDim.x && grp + gridDim.x >= ngroups) {
+            switch (((grp - (ngroups - gridDim.x)) * 4u) / gridDim.x) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+            }
+        }
+#endif
 #ifdef VIT_DIAG_TIMES
         const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
         unsigned long long diag_tr = 0;  // time spent in in-flight parts
@@ -1192,46 +1211,49 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
         {
             auto sa = load_step<SYM32>(a_sym, tau, tau < a_T), sb = load_step<SYM32>(b_sym, tau, tau < b_T);
             u32 v = 0;
-            for (u32 rb = 0; rb < nblk; rb++) {
-#if VIT_LONG_ROT
-                if (VIT_LONG_ROT == 3 ? true : VIT_LONG_ROT == 2 ? ngroups <= gridDim.x : grp + gridDim.x >= ngroups) {
-                    switch ((prio_slot + rb) & 3u) {
+            // Two blocks per trip - the pre-pass's 32 steps: the even block reads table half 0, the odd one half 1 (see vit_pk_kernel:
+            // the copies of loop-carried values once per pair).  In-flight parts start behind ODD blocks only: the table is dead there.
+            const bool last6 = VIT_STEPS6 && (T_max & 15u) == 6u;  // the frame's last block has six steps
+            const bool rot = VIT_LONG_ROT != 0 && (VIT_LONG_ROT == 3 ? true : VIT_LONG_ROT == 2 ? ngroups <= gridDim.x : grp + gridDim.x >= ngroups);
+            auto rotate = [&](const u32 rbx) {
+                if (rot) {
+                    switch ((prio_slot + rbx) & 3u) {
                         case 0: __builtin_amdgcn_s_setprio(0); break;
                         case 1: __builtin_amdgcn_s_setprio(1); break;
                         case 2: __builtin_amdgcn_s_setprio(2); break;
                         default: __builtin_amdgcn_s_setprio(3); break;
                     }
                 }
-#endif
-                if ((rb & 1u) == 0) {
-                    wave_sync();
-                    prepass(pack_step(sa), pack_step(sb), tab, PL, sel);
-                    const u32 tn = (rb + 2u) * 16u + tau;
-                    sa = load_step<SYM32>(a_sym, tn, tn < a_T);
-                    sb = load_step<SYM32>(b_sym, tn, tn < b_T);
-                    wave_sync();
-                }
-#if VIT_TAB_STATIC
-                if (VIT_STEPS6 && rb + 1u == nblk && (T_max & 15u) == 6u) {
-                    if (rb & 1u) steps6(v, A, B, acc0, acc1, tab, L1, lane, C);
-                    else steps6(v, A, B, acc0, acc1, tab, L, lane, C);
-                } else {
-                    if (rb & 1u) steps16<true>(v, A, B, acc0, acc1, tab, L1, lane, C);
-                    else steps16<true>(v, A, B, acc0, acc1, tab, L, lane, C);
-                }
-#else
-                if (VIT_STEPS6 && rb + 1u == nblk && (T_max & 15u) == 6u)
-                    steps6(v, A, B, acc0, acc1, tab + (rb & 1u) * 1024u, L, lane, C);
-                else
-                    steps16<true>(v, A, B, acc0, acc1, tab + (rb & 1u) * 1024u, L, lane, C);
-#endif
+            };
+            // a finished block's history words: the write-only spill, and the window (LDS slot or carry)
+            auto put = [&](const u32 rbx) {
                 const uint2 hw = make_uint2(acc1, acc0);  // the order of the LDS blocks: a reload is a plain copy
-                if (rb < G) wspill[(size_t)rb * 64u] = hw;
-                const int d = (int)rb - base;  // position in the window (< 0: a block no later part of this wave needs in LDS)
-                if (d >= 0 && d < (int)DUMP_GROUP) *reinterpret_cast<uint2*>(dec + (u32)d * DEC_BLOCK + dslot) = hw;
-                carry_put(cy, d, acc1, acc0);
+                if (rbx < G) wspill[(size_t)rbx * 64u] = hw;
+                const int dx = (int)rbx - base;  // position in the window (< 0: a block no later part of this wave needs in LDS)
+                if (dx >= 0 && dx < (int)DUMP_GROUP) *reinterpret_cast<uint2*>(dec + (u32)dx * DEC_BLOCK + dslot) = hw;
+                carry_put(cy, dx, acc1, acc0);
+            };
+            for (u32 rb0 = 0; rb0 < nblk; rb0 += 2u) {
+                rotate(rb0);
+                wave_sync();
+                prepass(pack_step(sa), pack_step(sb), tab, PL, sel);
+                const u32 tn = (rb0 + 2u) * 16u + tau;
+                sa = load_step<SYM32>(a_sym, tn, tn < a_T);
+                sb = load_step<SYM32>(b_sym, tn, tn < b_T);
+                wave_sync();
+                if (last6 && rb0 + 1u == nblk) steps6(v, A, B, acc0, acc1, tab, L, lane, C);
+                else steps16<true>(v, A, B, acc0, acc1, tab, L, lane, C);
+                put(rb0);
+                v = v == 4 ? 0 : v + 1;
+                if (rb0 + 1u >= nblk) break;
+                const u32 rb = rb0 + 1u;  // the odd block
+                rotate(rb);
+                if (last6 && rb + 1u == nblk) steps6(v, A, B, acc0, acc1, tab, L1, lane, C);
+                else steps16<true>(v, A, B, acc0, acc1, tab, L1, lane, C);
+                put(rb);
+                const int d = (int)rb - base;
                 // part p_next is traced in flight after the first ODD block (the table is dead then) that is >= two blocks above its top
-                if (p_next && d >= (int)LONG_LDS_BLOCKS + 1 && (rb & 1u)) {
+                if (p_next && d >= (int)LONG_LDS_BLOCKS + 1) {
                     const u32 hi = T_max - 256u * p_next;
                     const u32 lo = hi > 256u + VIT_TAIL ? hi - 256u : VIT_TAIL;
                     const u32 nc = (u32)d - (DUMP_GROUP - 1u);  // carried blocks: 3 or 4

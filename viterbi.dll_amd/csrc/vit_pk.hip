@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
                                                              u32 framebits_uniform, long long nframes, PkLayout lay,
                                                              uint2* spill, u32 spill_blocks, unsigned* counter,
                                                              u32 ngroups, u32 short_max,
-                                                             const unsigned* __restrict__ split_gate, u32 renorm_c) {
+                                                             const unsigned* __restrict__ split_gate, u32 renorm_c, u32 nsimd) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* dec = lds;                  // 16 blocks; 17th ... 20th land on the table when it is dead
     char* tab = lds + lay.dec_bytes;  // [tau][pair][c] -> M; after the ACS: last block, scratch, image
@@ -1085,13 +1085,13 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
 #ifndef VIT_LONG_ROT
 #define VIT_LONG_ROT 2  /* 0: no issue priorities in this kernel, 2: rotating priorities in a one-round launch, 1: in the last round of every launch */
 #endif
-#if VIT_LONG_ROT
     u32 prio_slot;
     {
         u32 hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         prio_slot = hwid & 3u;  // wave slot within the SIMD
     }
+#if VIT_LONG_ROT
 #if VIT_LONG_BASE_PRIO
     // every wave of this kernel at the level of the single-segment kernel's three regular waves: when a split table runs both kernels
     // side by side, the few long groups are the critical path and must not rank below the other kernel's waves
@@ -1229,7 +1229,8 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
             // Two blocks per trip - the pre-pass's 32 steps: the even block reads table half 0, the odd one half 1 (see vit_pk_kernel:
             // the copies of loop-carried values once per pair).  In-flight parts start behind ODD blocks only: the table is dead there.
             const bool last6 = VIT_STEPS6 && (T_max & 15u) == 6u;  // the frame's last block has six steps
-            const bool rot = VIT_LONG_ROT != 0 && (VIT_LONG_ROT == 3 ? true : VIT_LONG_ROT == 2 ? ngroups <= gridDim.x : grp + gridDim.x >= ngroups);
+            // (a launch of at most one wave per SIMD - ngroups <= nsimd - has nothing to rotate between, and the s_setprio per block costs it 4.5 %)
+            const bool rot = VIT_LONG_ROT != 0 && (VIT_LONG_ROT == 3 ? true : VIT_LONG_ROT == 2 ? (ngroups <= gridDim.x && ngroups > nsimd) : grp + gridDim.x >= ngroups);
             auto rotate = [&](const u32 rbx) {
                 if (rot) {
                     switch ((prio_slot + rbx) & 3u) {
@@ -1645,11 +1646,11 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
         if (sym32)
             hipLaunchKernelGGL(vit_pk_long_kernel<true>, dim3((unsigned)grid), dim3(64), lay.total, ls, d_sym, d_out,
                                d_desc, framebits, (long long)nframes, lay, spill, spill_blocks, counter, (u32)groups,
-                               short_max, gate, rc);
+                               short_max, gate, rc, 4u * (u32)vit_device_cus(dev));
         else
             hipLaunchKernelGGL(vit_pk_long_kernel<false>, dim3((unsigned)grid), dim3(64), lay.total, ls, d_sym, d_out,
                                d_desc, framebits, (long long)nframes, lay, spill, spill_blocks, counter, (u32)groups,
-                               short_max, gate, rc);
+                               short_max, gate, rc, 4u * (u32)vit_device_cus(dev));
         if (short_max && (e = hipGetLastError()) == hipSuccess) {
             const PkLayout lsh = pk_layout(PK_SHORT_MAX);
             launch_short(groups, lsh, max_framebits, gate, false);  // shares the chip with the long-frame kernel: static priorities

@@ -1576,7 +1576,8 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
     auto launch_short = [&](long long g, const PkLayout& l, u32 vmax, const unsigned* gate, bool may_rotate) {
         u32 per_cu = (160u * 1024u) / l.total;
         if (per_cu > 16u) per_cu = 16u;  // 4 waves per SIMD (launch bounds)
-        const bool rot = may_rotate && g <= (long long)per_cu * vit_device_cus(dev);
+        // (a launch of at most one wave per SIMD has nothing to rotate between, and the s_setprio per block costs it time)
+        const bool rot = may_rotate && g <= (long long)per_cu * vit_device_cus(dev) && g > 4ll * vit_device_cus(dev);
 #define VIT_LAUNCH_SHORT(S32, R)                                                                                          \
     hipLaunchKernelGGL((vit_pk_kernel<S32, R>), dim3((unsigned)g), dim3(64), l.total, stream, d_sym, d_out, d_desc, framebits, \
                        (long long)nframes, l, vmax, gate, rc)

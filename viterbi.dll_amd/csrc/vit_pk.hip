@@ -50,7 +50,10 @@
 // maps measured (four distinct levels starve the lowest: 63 ... 248 us per wave and a 50 us drain).  In a launch of ONE round
 // nothing replaces a finished wave, so the priority rotates block by block and the four waves finish together (a separate
 // instantiation of the single-segment kernel; a run-time branch in the persistent long-frame kernel, whose workgroups also take
-// their first group statically instead of queueing at one atomic counter).
+// their first group statically instead of queueing at one atomic counter).  Round 4 (profiles/r04_ab_long_inflight.txt, sections 13-21): the
+// persistent kernel's multi-round launches follow "more work left -> more issue slots" - in a uniform launch the last round of
+// fetches runs at a priority that grows with the fetch order, in a length-sorted table the long groups run above the short ones -;
+// an s_setprio per block is not free, so launches of at most one wave per SIMD do not rotate.
 //
 // Instruction costs that shaped this (profiles/r01_valu_issue_rates_ubench.txt): v_pk_*,
 // VOP3 three-operand, DPP, SDWA, v_cmp = 4 cycles per wave; plain VOP2 = 2;

@@ -66,7 +66,7 @@ fbs = 96 * rng.integers(3, 73, n)
 desc, sym_bytes, out_bytes = V.make_descs(fbs.tolist())
 d_desc = torch.from_numpy(desc.view(np.uint8)).to(dev)
 so_all = torch.from_numpy(desc["sym_offset"].astype(np.int64)).to(dev)
-mx = int(fbs.max())
+mx = int(os.environ.get("CFG3_MAX", fbs.max()))  # CFG3_MAX: a caller that declares a generous max_framebits (e.g. 9216)
 ref = None
 for label in LABELS:
     sym = torch.empty(sym_bytes, dtype=torch.uint8, device=dev)

@@ -1195,8 +1195,11 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
         // 0 dB and on input without signal; with the 1/2 threshold alone or thresholds of 7/8 and 3/4: nothing
         // (profiles/r04_ab_long_inflight.txt, section 19).  A table of equal lengths runs at one level throughout, as before.
         if (desc && ngroups > gridDim.x) {
-            if ((unsigned long long)maxfb * 4ull > (unsigned long long)lay.maxfb * 3ull) __builtin_amdgcn_s_setprio(3);
-            else if ((unsigned long long)maxfb * 2ull > (unsigned long long)lay.maxfb) __builtin_amdgcn_s_setprio(2);
+            // the launch's longest frame: the first descriptor of the (sorted) table; what the caller declared as max_framebits may be generous
+            u32 ref = desc[0].framebits;
+            if (ref > lay.maxfb || ref < maxfb) ref = lay.maxfb;
+            if ((unsigned long long)maxfb * 4ull > (unsigned long long)ref * 3ull) __builtin_amdgcn_s_setprio(3);
+            else if ((unsigned long long)maxfb * 2ull > (unsigned long long)ref) __builtin_amdgcn_s_setprio(2);
             else __builtin_amdgcn_s_setprio(1);
         }
 #endif

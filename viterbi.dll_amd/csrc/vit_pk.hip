@@ -1137,7 +1137,9 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
         // (profiles/r04_ab_long_inflight.txt, section 13) it takes 3-11 % off 2.5 ... 5 rounds (config 5's decode, 5 rounds: -3 %), is within
         // +-2 % from 5.5 rounds up, costs 7 % at exactly two rounds (all waves fetch together: the levels only unbalance them) and 2-3 % on a
         // length-sorted table, whose last fetches are its shortest frames.
-        if (!desc && (unsigned long long)ngroups * 4ull >= 9ull * gridDim.x && grp + gridDim.x >= ngroups) {
+        // (a sorted table whose first and last frame are equally long is a uniform launch too)
+        const bool uniform_launch = !desc || desc[0].framebits == desc[nframes - 1].framebits;
+        if (uniform_launch && (unsigned long long)ngroups * 4ull >= 9ull * gridDim.x && grp + gridDim.x >= ngroups) {
             switch (((grp - (ngroups - gridDim.x)) * 4u) / gridDim.x) {
                 case 0: __builtin_amdgcn_s_setprio(0); break;
                 case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -1194,7 +1196,7 @@ __global__ __launch_bounds__(64, 4) void vit_pk_long_kernel(const uint8_t* __res
         // finish sooner, the dynamic counter levels the short ones behind them.  Config 3 as drawn: 1.125 -> 1.058 ms at 3 dB, the same 6 % at
         // 0 dB and on input without signal; with the 1/2 threshold alone or thresholds of 7/8 and 3/4: nothing
         // (profiles/r04_ab_long_inflight.txt, section 19).  A table of equal lengths runs at one level throughout, as before.
-        if (desc && ngroups > gridDim.x) {
+        if (desc && ngroups > gridDim.x && desc[0].framebits != desc[nframes - 1].framebits) {
             // the launch's longest frame: the first descriptor of the (sorted) table; what the caller declared as max_framebits may be generous
             u32 ref = desc[0].framebits;
             if (ref > lay.maxfb || ref < maxfb) ref = lay.maxfb;

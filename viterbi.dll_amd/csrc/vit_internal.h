@@ -54,8 +54,11 @@ hipError_t vit_launch_lat_ring(uint8_t* d_ring, const VitRingTable& tbl, uint32_
 // frames the latency kernel can keep resident at one wave per SIMD or so for this frame length (LDS-limited)
 int64_t vit_lat_capacity(uint32_t max_framebits, int dev);
 // Length-sorted (longest first) copy of a device descriptor table; d_bins = 2*VIT_SORT_BINS words of scratch.
+// bins_clean (optional): the caller's flag "the histogram half of d_bins is zero" - the scan kernel leaves it so; d_hdr (optional): 64
+// words the scan kernel clears (the persistent kernel's counter header in front of the bins).
 hipError_t vit_sort_descs_launch(const vit_frame_desc* d_desc, vit_frame_desc* d_sorted, int64_t nframes,
-                                 uint32_t max_framebits, unsigned* d_bins, hipStream_t stream);
+                                 uint32_t max_framebits, unsigned* d_bins, hipStream_t stream, bool* bins_clean = nullptr,
+                                 unsigned* d_hdr = nullptr);
 // Copy of a device descriptor table in which every descriptor that reaches outside [0, sym_bytes) / [0, out_bytes)
 // has its framebits replaced by 0xFFFFFFFF (skipped by every kernel).
 hipError_t vit_check_descs_launch(const vit_frame_desc* d_desc, vit_frame_desc* d_checked, int64_t nframes,

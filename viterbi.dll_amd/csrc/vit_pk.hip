@@ -1512,6 +1512,7 @@ struct ScratchCtx {
     int dev = -1;
     // a split table runs its two kernels side by side: the long-frame kernel goes to `side`, forked from and joined
     // back into the caller's stream with these events
+    bool bins_clean = false;  // the sort's histogram in this buffer is zero (the scan kernel leaves it so)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void drop_side() {
@@ -1611,6 +1612,7 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
         if (sc.buf) (void)hipFree(sc.buf);  // synchronises with the kernels still using it
         sc.buf = nullptr;
         sc.cap = 0;
+        sc.bins_clean = false;
         if (sc.ev) (void)hipEventDestroy(sc.ev);
         sc.ev = nullptr;
         if ((e = hipMalloc(&sc.buf, need + need / 4)) != hipSuccess) return e;
@@ -1624,12 +1626,12 @@ hipError_t vit_launch_pk(const void* d_symbols, bool sym32, uint8_t* d_out, cons
     if (sort) {
         vit_frame_desc* sorted = reinterpret_cast<vit_frame_desc*>(base + SCRATCH_HDR);
         if ((e = vit_sort_descs_launch(d_desc, sorted, nframes, max_framebits, reinterpret_cast<unsigned*>(base + 256),
-                                       stream)) != hipSuccess)
+                                       stream, &sc.bins_clean, reinterpret_cast<unsigned*>(base))) != hipSuccess)
             return e;
         d_desc = sorted;
     }
     unsigned* counter = reinterpret_cast<unsigned*>(base);
-    if (need_counter && (e = hipMemsetAsync(base, 0, 256, stream)) != hipSuccess) return e;
+    if (need_counter && !sort && (e = hipMemsetAsync(base, 0, 256, stream)) != hipSuccess) return e;  // (the sort's scan kernel clears it)
     if (is_long) {
         // A length-sorted table is split between the two kernels: the long-frame kernel stops at the first group
         // that fits one segment, the single-segment kernel (second launch, same stream) skips the groups before it.

@@ -37,7 +37,9 @@ __global__ __launch_bounds__(TPB) void desc_hist_kernel(const vit_frame_desc* __
 }
 
 // hist[k] = count of key k  ->  start[k] = number of descriptors with a LARGER key (descending order)
-__global__ __launch_bounds__(256) void desc_scan_kernel(const unsigned* __restrict__ hist, unsigned* __restrict__ start) {
+// It also leaves the histogram zeroed for the next sort and clears the 256-byte header in front of it (the persistent kernel's group
+// counter): two memset dispatches less per call (profiles/r04_ab_long_inflight.txt, section 22).
+__global__ __launch_bounds__(256) void desc_scan_kernel(unsigned* __restrict__ hist, unsigned* __restrict__ start, unsigned* __restrict__ hdr) {
     constexpr u32 PER = (BINS + 255u) / 256u;  // 5 bins per thread, taken from the top
     __shared__ unsigned part[256];
     const u32 t = threadIdx.x;
@@ -46,8 +48,10 @@ __global__ __launch_bounds__(256) void desc_scan_kernel(const unsigned* __restri
     for (u32 j = 0; j < PER; j++) {
         const u32 r = t * PER + j;  // rank from the top: bin BINS-1-r
         c[j] = r < BINS ? hist[BINS - 1u - r] : 0u;
+        if (r < BINS) hist[BINS - 1u - r] = 0u;
         sum += c[j];
     }
+    if (hdr && t < 64u) hdr[t] = 0u;
     part[t] = sum;
     __syncthreads();
     for (u32 d = 1; d < 256u; d <<= 1) {  // inclusive Hillis-Steele scan over the thread sums
@@ -115,14 +119,18 @@ hipError_t vit_check_descs_launch(const vit_frame_desc* d_desc, vit_frame_desc* 
 }
 
 hipError_t vit_sort_descs_launch(const vit_frame_desc* d_desc, vit_frame_desc* d_sorted, int64_t nframes,
-                                 uint32_t max_framebits, unsigned* d_bins, hipStream_t stream) {
+                                 uint32_t max_framebits, unsigned* d_bins, hipStream_t stream, bool* bins_clean, unsigned* d_hdr) {
     if (nframes <= 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(d_bins, 0, 2u * BINS * sizeof(unsigned), stream);
-    if (e != hipSuccess) return e;
+    hipError_t e;
+    if (!bins_clean || !*bins_clean) {  // first sort in this buffer (or after a failed one): the histogram is not known to be zero
+        if ((e = hipMemsetAsync(d_bins, 0, BINS * sizeof(unsigned), stream)) != hipSuccess) return e;
+    }
+    if (bins_clean) *bins_clean = false;
     const unsigned blocks = (unsigned)((nframes + TPB - 1) / TPB);
     hipLaunchKernelGGL(desc_hist_kernel, dim3(blocks), dim3(TPB), 0, stream, d_desc, (long long)nframes, max_framebits,
                        d_bins);
-    hipLaunchKernelGGL(desc_scan_kernel, dim3(1), dim3(256), 0, stream, d_bins, d_bins + BINS);
+    hipLaunchKernelGGL(desc_scan_kernel, dim3(1), dim3(256), 0, stream, d_bins, d_bins + BINS, d_hdr);
+    if (bins_clean && hipPeekAtLastError() == hipSuccess) *bins_clean = true;  // the scan leaves the histogram zeroed
     hipLaunchKernelGGL(desc_scatter_kernel, dim3(blocks), dim3(TPB), 0, stream, d_desc, (long long)nframes,
                        max_framebits, d_bins + BINS, d_sorted);
     return hipGetLastError();
